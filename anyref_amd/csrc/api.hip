@@ -1,0 +1,116 @@
+// extern "C" boundary of libanyref_hip.so (include/anyref_hip.h).  Exceptions never cross it:
+// every entry point returns a status and stores the text for anyref_last_error().
+#include <cstring>
+#include <string>
+
+#include "model.h"
+
+using namespace anyref;
+
+struct anyref_handle {
+  std::unique_ptr<ModelBase> m;
+  std::string err;
+};
+
+static thread_local std::string g_create_err;
+
+#define GUARD(h, body)                         \
+  if (!(h) || !(h)->m) return 1;               \
+  try {                                        \
+    body;                                      \
+    hipError_t _e = hipGetLastError();         \
+    if (_e != hipSuccess) {                    \
+      (h)->err = std::string("HIP error: ") + hipGetErrorString(_e); \
+      return 3;                                \
+    }                                          \
+    return 0;                                  \
+  } catch (const std::exception& e) {          \
+    (h)->err = e.what();                       \
+    return 2;                                  \
+  }
+
+extern "C" {
+
+int anyref_create(const anyref_config* cfg, int device, anyref_handle** out) {
+  try {
+    if (!cfg || !out) throw std::runtime_error("null argument");
+    if (cfg->abi_version != ANYREF_ABI_VERSION) throw std::runtime_error("anyref_config ABI version mismatch");
+    if (cfg->max_batch < 1 || cfg->max_seg < 1) throw std::runtime_error("max_batch / max_seg must be >= 1");
+    if (cfg->llm_dim % cfg->llm_heads || cfg->clip_dim % cfg->clip_heads || cfg->sam_dim % cfg->sam_heads)
+      throw std::runtime_error("hidden sizes must be divisible by the head counts");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+      throw std::runtime_error("no HIP device visible: the AnyRef HIP backend needs an MI355X (there is no CPU fallback)");
+    if (device < 0 || device >= ndev) throw std::runtime_error("device index out of range");
+    auto* h = new anyref_handle();
+    h->m = make_model(*cfg, device);
+    *out = h;
+    return 0;
+  } catch (const std::exception& e) {
+    g_create_err = e.what();
+    return 2;
+  }
+}
+
+void anyref_destroy(anyref_handle* h) { delete h; }
+
+const char* anyref_last_error(anyref_handle* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+int anyref_set_weight(anyref_handle* h, const char* name, const void* ptr, int is_device, int dtype,
+                      const int64_t* shape, int ndim) {
+  GUARD(h, h->m->set_weight(name, ptr, is_device, dtype, shape, ndim));
+}
+
+int anyref_finalize(anyref_handle* h) { GUARD(h, h->m->finalize()); }
+
+int anyref_generate(anyref_handle* h, void* stream, const float* clip_images, const float* sam_images,
+                    const int64_t* input_ids, const int32_t* lens, int B, int Lmax, const float* extra_embeds,
+                    const int32_t* extra_slots, int n_extra, const int32_t* resized_hw, const int32_t* orig_hw,
+                    int max_new_tokens, int eos_token_id, int64_t* out_ids, int32_t* out_lens, int32_t* out_nseg,
+                    float* out_masks, int64_t out_masks_cap, int64_t* mask_offsets, float* out_low,
+                    float* out_hidden) {
+  GUARD(h, h->m->generate((hipStream_t)stream, clip_images, sam_images, input_ids, lens, B, Lmax, extra_embeds,
+                          extra_slots, n_extra, resized_hw, orig_hw, max_new_tokens, eos_token_id, out_ids,
+                          out_lens, out_nseg, out_masks, out_masks_cap, mask_offsets, out_low, out_hidden));
+}
+
+int anyref_forward_teacher(anyref_handle* h, void* stream, const float* clip_images, const float* sam_images,
+                           const int64_t* input_ids, const int32_t* lens, int B, int Lmax,
+                           const float* extra_embeds, const int32_t* extra_slots, int n_extra,
+                           const int32_t* rephrase_start, const int32_t* resized_hw, const int32_t* orig_hw,
+                           int32_t* out_nseg, float* out_masks, int64_t out_masks_cap, int64_t* mask_offsets,
+                           float* out_low, float* out_hidden, float* out_logits) {
+  GUARD(h, h->m->forward_teacher((hipStream_t)stream, clip_images, sam_images, input_ids, lens, B, Lmax,
+                                 extra_embeds, extra_slots, n_extra, rephrase_start, resized_hw, orig_hw, out_nseg,
+                                 out_masks, out_masks_cap, mask_offsets, out_low, out_hidden, out_logits));
+}
+
+int anyref_encode_images(anyref_handle* h, void* stream, const float* clip_images, int B, float* out,
+                         float* clip_feat) {
+  GUARD(h, h->m->encode_images((hipStream_t)stream, clip_images, B, out, clip_feat));
+}
+
+int anyref_sam_encode(anyref_handle* h, void* stream, const float* sam_images, int B, float* out) {
+  GUARD(h, h->m->sam_encode((hipStream_t)stream, sam_images, B, out));
+}
+
+int anyref_mask_decode(anyref_handle* h, void* stream, const float* image_emb, const float* pred_emb, int n,
+                       float* masks4, float* iou, const int32_t* resized_hw, const int32_t* orig_hw,
+                       float* out_masks) {
+  GUARD(h, h->m->mask_decode((hipStream_t)stream, image_emb, pred_emb, n, masks4, iou, resized_hw, orig_hw, out_masks));
+}
+
+int anyref_llm_forward(anyref_handle* h, void* stream, const float* embeds, const int32_t* lens, int B, int S,
+                       float* hidden, float* logits, const int32_t* attn_q, float* attn_row) {
+  GUARD(h, h->m->llm_forward((hipStream_t)stream, embeds, lens, B, S, hidden, logits, attn_q, attn_row));
+}
+
+int anyref_project_audio(anyref_handle* h, void* stream, const float* audio_emb, int n, float* out) {
+  GUARD(h, h->m->project_audio((hipStream_t)stream, audio_emb, n, out));
+}
+
+int64_t anyref_device_bytes(anyref_handle* h) { return h && h->m ? h->m->device_bytes() : 0; }
+
+const char* anyref_mode_name(anyref_handle* h) { return h && h->m ? h->m->mode_name() : ""; }
+
+}  // extern "C"

@@ -1,0 +1,397 @@
+// Fused multi-head attention for gfx950 (flash-style, online softmax, scores never leave the CU).
+//
+// One source serves every attention on the path through strides + template head dim:
+//   CLIP (257 tok, hd 64), LLaMA causal prefill + KV-cache decode (hd 128), SAM windowed /
+//   global with decomposed rel-pos bias (hd 80/64), the mask decoder's 6x4096 / 4096x6 / 6x6
+//   cross/self attention (hd 16/32).
+// T = bf16 -> v_mfma_f32_16x16x32_bf16, T = float -> v_mfma_f32_16x16x4_f32 (parity mode).
+//
+// Workgroup = 4 waves = 64 query rows (16 per wave, Q fragments live in registers); K/V tiles of
+// BKV keys go through LDS (V transposed for the bf16 B-operand), S = QK^T and O += PV on MFMA,
+// softmax statistics per row in registers (rows sit on 16-lane groups of the C layout).
+#include "kernels.h"
+
+namespace anyref {
+
+template <typename T>
+struct AMma;
+template <>
+struct AMma<bf16> {
+  static constexpr int KS = 32, VEC = 8;
+  using Frag = short8;
+  static __device__ inline Frag lds(const bf16* p, int lane) {
+    return *reinterpret_cast<const short8*>(p + 8 * (lane >> 4));
+  }
+  // fragment straight from a global row (guarded): elements [k0 + 8*(lane>>4), +8)
+  static __device__ inline Frag glb(const bf16* row, int k0, int lane, bool ok, int HD) {
+    const int d = k0 + 8 * (lane >> 4);
+    if (ok && d < HD) return *reinterpret_cast<const short8*>(row + d);
+    return short8{0, 0, 0, 0, 0, 0, 0, 0};
+  }
+  static __device__ inline float4v mma(Frag a, Frag b, float4v c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+  static __device__ inline float fexp(float x) { return __expf(x); }
+};
+template <>
+struct AMma<float> {
+  static constexpr int KS = 4, VEC = 4;
+  using Frag = float;
+  static __device__ inline Frag lds(const float* p, int lane) { return p[lane >> 4]; }
+  static __device__ inline Frag glb(const float* row, int k0, int lane, bool ok, int HD) {
+    const int d = k0 + (lane >> 4);
+    return (ok && d < HD) ? row[d] : 0.f;
+  }
+  static __device__ inline float4v mma(Frag a, Frag b, float4v c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+  static __device__ inline float fexp(float x) { return expf(x); }
+};
+
+template <typename T>
+struct AttnTile {
+  static constexpr int BKV = sizeof(T) == 2 ? 64 : 32;
+};
+
+template <typename T, int HD>
+__global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
+  using M_ = AMma<T>;
+  constexpr int KS = M_::KS, VEC = M_::VEC;
+  constexpr int BKV = AttnTile<T>::BKV;
+  constexpr int HDK = (HD + KS - 1) / KS * KS;  // QK^T contraction length (zero padded)
+  constexpr int LDK = HDK + VEC;                // K tile row stride
+  constexpr bool VT = sizeof(T) == 2;           // bf16: V stored transposed [d][key]
+  constexpr int LDV = VT ? BKV + VEC : HD + VEC;
+  constexpr int LDP = BKV + VEC;
+  constexpr int NB = BKV / 16;  // key blocks of one tile
+  constexpr int DB = HD / 16;   // output d blocks
+  static_assert(HD % 16 == 0, "head dim must be a multiple of 16");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* Ks = reinterpret_cast<T*>(smem);
+  T* Vs = Ks + BKV * LDK;
+  T* Ps = Vs + (VT ? HD * LDV : BKV * LDV);
+  float* relh_s = reinterpret_cast<float*>(Ps + 4 * 16 * LDP);
+  float* relw_s = relh_s + 64 * a.kh;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
+  const int kv_len = a.kv_len ? a.kv_len[b] : a.Sk;
+  const int q_len = a.q_len ? a.q_len[b] : a.Sq;
+  if (q0 >= q_len) return;  // uniform per workgroup
+  const int pos0 = a.q_pos0 ? a.q_pos0[b] : 0;
+  int kv_end = kv_len;
+  if (a.causal) {
+    const int imax = (q0 + 64 < q_len ? q0 + 64 : q_len) - 1;
+    if (pos0 + imax + 1 < kv_end) kv_end = pos0 + imax + 1;
+  }
+
+  const T* Qb = reinterpret_cast<const T*>(a.Q) + (int64_t)b * a.q_bs + (int64_t)h * a.q_hs;
+  const T* Kb = reinterpret_cast<const T*>(a.K) + (int64_t)b * a.k_bs + (int64_t)h * a.k_hs;
+  const T* Vb = reinterpret_cast<const T*>(a.V) + (int64_t)b * a.v_bs + (int64_t)h * a.v_hs;
+
+  // Q fragments (A operand): row = lane&15 of this wave's 16 rows
+  typename M_::Frag qf[HDK / KS];
+  {
+    const int qr = q0 + wave * 16 + (lane & 15);
+    const bool ok = qr < q_len;
+    const T* qrow = Qb + (int64_t)(ok ? qr : 0) * a.q_rs;
+#pragma unroll
+    for (int kk = 0; kk < HDK / KS; ++kk) qf[kk] = M_::glb(qrow, kk * KS, lane, ok, HD);
+  }
+  const bool has_rel = a.rel_h != nullptr;
+  if (has_rel) {
+    const float* rh = a.rel_h + ((int64_t)b * a.H + h) * a.Sq * a.kh;
+    const float* rw = a.rel_w + ((int64_t)b * a.H + h) * a.Sq * a.kw;
+    for (int i = tid; i < 64 * a.kh; i += 256) {
+      const int r = i / a.kh, c = i % a.kh;
+      relh_s[i] = q0 + r < q_len ? rh[(int64_t)(q0 + r) * a.kh + c] : 0.f;
+    }
+    for (int i = tid; i < 64 * a.kw; i += 256) {
+      const int r = i / a.kw, c = i % a.kw;
+      relw_s[i] = q0 + r < q_len ? rw[(int64_t)(q0 + r) * a.kw + c] : 0.f;
+    }
+  }
+
+  float m_run[4], l_run[4];
+  float4v o[DB];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    m_run[r] = -INFINITY;
+    l_run[r] = 0.f;
+  }
+#pragma unroll
+  for (int d = 0; d < DB; ++d) o[d] = float4v{0.f, 0.f, 0.f, 0.f};
+
+  T* Pw = Ps + wave * 16 * LDP;
+  const int irow0 = wave * 16 + 4 * (lane >> 4);  // local q row of acc element r=0
+
+  for (int kt = 0; kt < kv_end; kt += BKV) {
+    // ---- stage K [BKV][HDK] and V ---------------------------------------------------------
+    constexpr int KVEC = HDK / VEC;
+    for (int v = tid; v < BKV * KVEC; v += 256) {
+      const int row = v / KVEC, d = (v % KVEC) * VEC;
+      const int j = kt + row;
+      uint4v val = uint4v{0, 0, 0, 0};
+      if (j < kv_end && d < HD) val = *reinterpret_cast<const uint4v*>(Kb + (int64_t)j * a.k_rs + d);
+      *reinterpret_cast<uint4v*>(&Ks[row * LDK + d]) = val;
+    }
+    constexpr int VVEC = HD / VEC;
+    for (int v = tid; v < BKV * VVEC; v += 256) {
+      const int row = v / VVEC, d = (v % VVEC) * VEC;
+      const int j = kt + row;
+      uint4v val = uint4v{0, 0, 0, 0};
+      if (j < kv_end) val = *reinterpret_cast<const uint4v*>(Vb + (int64_t)j * a.v_rs + d);
+      if constexpr (VT) {
+        const uint16_t* e = reinterpret_cast<const uint16_t*>(&val);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) reinterpret_cast<uint16_t*>(Vs)[(d + i) * LDV + row] = e[i];
+      } else {
+        *reinterpret_cast<uint4v*>(&Vs[row * LDV + d]) = val;
+      }
+    }
+    __syncthreads();
+
+    // ---- S = Q K^T ----------------------------------------------------------------------------
+    float4v sc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      sc[nb] = float4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < HDK / KS; ++kk)
+        sc[nb] = M_::mma(qf[kk], M_::lds(&Ks[(nb * 16 + (lane & 15)) * LDK + kk * KS], lane), sc[nb]);
+    }
+    // ---- scale, bias, mask, online softmax ----------------------------------------------------
+    int jh[NB], jw[NB];
+    if (has_rel) {
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const int j = kt + nb * 16 + (lane & 15);
+        jh[nb] = j / a.kw;
+        jw[nb] = j % a.kw;
+        if (jh[nb] >= a.kh) {  // masked keys beyond kv_len: keep LDS reads in range
+          jh[nb] = 0;
+          jw[nb] = 0;
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int il = irow0 + r, i = q0 + il;
+      float mx = -INFINITY;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const int j = kt + nb * 16 + (lane & 15);
+        float s = sc[nb][r] * a.scale;
+        if (has_rel) s += relh_s[il * a.kh + jh[nb]] + relw_s[il * a.kw + jw[nb]];
+        const bool valid = j < kv_len && (!a.causal || j <= pos0 + i);
+        s = valid ? s : -INFINITY;
+        sc[nb][r] = s;
+        mx = fmaxf(mx, s);
+      }
+#pragma unroll
+      for (int off = 1; off < 16; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+      const float m_new = fmaxf(m_run[r], mx);
+      const float mref = m_new == -INFINITY ? 0.f : m_new;
+      const float alpha = M_::fexp(m_run[r] - mref);  // m_run = -inf -> 0
+      float rs = 0.f;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const float p = M_::fexp(sc[nb][r] - mref);  // masked: exp(-inf) = 0
+        rs += p;
+        Pw[(4 * (lane >> 4) + r) * LDP + nb * 16 + (lane & 15)] = from_f32<T>(p);
+      }
+      l_run[r] = l_run[r] * alpha + rs;
+      m_run[r] = m_new;
+#pragma unroll
+      for (int d = 0; d < DB; ++d) o[d][r] *= alpha;
+    }
+    __syncthreads();  // P visible (wave-local data, but keeps the LDS ordering simple)
+
+    // ---- O += P V ---------------------------------------------------------------------------
+#pragma unroll
+    for (int kk = 0; kk < BKV / KS; ++kk) {
+      const typename M_::Frag pf = M_::lds(&Pw[(lane & 15) * LDP + kk * KS], lane);
+#pragma unroll
+      for (int d = 0; d < DB; ++d) {
+        typename M_::Frag vf;
+        if constexpr (VT)
+          vf = M_::lds(&Vs[(d * 16 + (lane & 15)) * LDV + kk * KS], lane);
+        else
+          vf = Vs[(kk * KS + (lane >> 4)) * LDV + d * 16 + (lane & 15)];
+        o[d] = M_::mma(pf, vf, o[d]);
+      }
+    }
+    __syncthreads();  // K/V/P tiles free for the next iteration
+  }
+
+  // ---- normalise + store --------------------------------------------------------------------
+  T* Ob = reinterpret_cast<T*>(a.O) + (int64_t)b * a.o_bs + (int64_t)h * a.o_hs;
+  float* Obf = reinterpret_cast<float*>(a.O) + (int64_t)b * a.o_bs + (int64_t)h * a.o_hs;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float l = l_run[r];
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) l += __shfl_xor(l, off, 64);
+    const int i = q0 + irow0 + r;
+    if (i >= q_len) continue;
+    const float inv = l > 0.f ? 1.f / l : 0.f;
+#pragma unroll
+    for (int d = 0; d < DB; ++d) {
+      const int64_t off = (int64_t)i * a.o_rs + d * 16 + (lane & 15);
+      if (a.o_f32)
+        Obf[off] = o[d][r] * inv;
+      else
+        Ob[off] = from_f32<T>(o[d][r] * inv);
+    }
+  }
+}
+
+template <typename T, int HD>
+static void attn_launch(const AttnArgs& a, hipStream_t s) {
+  constexpr int KS = AMma<T>::KS, VEC = AMma<T>::VEC, BKV = AttnTile<T>::BKV;
+  constexpr int HDK = (HD + KS - 1) / KS * KS, LDK = HDK + VEC;
+  constexpr bool VT = sizeof(T) == 2;
+  constexpr int LDV = VT ? BKV + VEC : HD + VEC, LDP = BKV + VEC;
+  size_t lds = sizeof(T) * (BKV * LDK + (VT ? HD * LDV : BKV * LDV) + 4 * 16 * LDP);
+  if (a.rel_h) lds += sizeof(float) * 64 * (a.kh + a.kw);
+  if (lds > 160 * 1024) throw std::runtime_error("attention: LDS budget exceeded");
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<T, HD>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  dim3 grid(cdiv(a.Sq, 64), a.H, a.B);
+  hipLaunchKernelGGL((attn_kernel<T, HD>), grid, dim3(256), lds, s, a);
+}
+
+template <typename T>
+void launch_attention(const AttnArgs& a, hipStream_t s) {
+  if (a.B <= 0 || a.Sq <= 0) return;
+  constexpr int VEC = AMma<T>::VEC;
+  if (a.q_rs % VEC || a.k_rs % VEC || a.v_rs % VEC || a.q_hs % VEC || a.k_hs % VEC || a.v_hs % VEC ||
+      a.q_bs % VEC || a.k_bs % VEC || a.v_bs % VEC)
+    throw std::runtime_error("attention: strides must be multiples of 16 bytes");
+  switch (a.hd) {
+    case 16: attn_launch<T, 16>(a, s); break;
+    case 32: attn_launch<T, 32>(a, s); break;
+    case 64: attn_launch<T, 64>(a, s); break;
+    case 80: attn_launch<T, 80>(a, s); break;
+    case 128: attn_launch<T, 128>(a, s); break;
+    default: throw std::runtime_error("attention: unsupported head dim (16/32/64/80/128)");
+  }
+}
+template void launch_attention<float>(const AttnArgs&, hipStream_t);
+template void launch_attention<bf16>(const AttnArgs&, hipStream_t);
+
+// ---------------------------------------------------------------------------------------------
+// Head-mean attention row of one query (rephrase branch).  One workgroup per batch element.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void attn_row_mean_kernel(const T* __restrict__ q, int64_t q_bs, int64_t q_hs,
+                                                            const T* __restrict__ K, int64_t k_bs, int64_t k_rs,
+                                                            int64_t k_hs, const int* __restrict__ kv_len, int H,
+                                                            int hd, float scale, float* __restrict__ out,
+                                                            int ld_out) {
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = kv_len[b];
+  __shared__ float red[4];
+  __shared__ float qs[256];
+  float* o = out + (int64_t)b * ld_out;
+  for (int j = tid; j < n; j += 256) o[j] = 0.f;
+  for (int h = 0; h < H; ++h) {
+    __syncthreads();
+    for (int d = tid; d < hd; d += 256) qs[d] = to_f32<T>(q[(int64_t)b * q_bs + (int64_t)h * q_hs + d]);
+    __syncthreads();
+    // pass 1: max
+    float mx = -INFINITY;
+    for (int j = tid; j < n; j += 256) {
+      const T* kr = K + (int64_t)b * k_bs + (int64_t)j * k_rs + (int64_t)h * k_hs;
+      float s = 0.f;
+      for (int d = 0; d < hd; ++d) s = fmaf(qs[d], to_f32<T>(kr[d]), s);
+      mx = fmaxf(mx, s * scale);
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float sum = 0.f;
+    for (int j = tid; j < n; j += 256) {
+      const T* kr = K + (int64_t)b * k_bs + (int64_t)j * k_rs + (int64_t)h * k_hs;
+      float s = 0.f;
+      for (int d = 0; d < hd; ++d) s = fmaf(qs[d], to_f32<T>(kr[d]), s);
+      sum += expf(s * scale - mx);
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) red[wave] = sum;
+    __syncthreads();
+    sum = red[0] + red[1] + red[2] + red[3];
+    for (int j = tid; j < n; j += 256) {
+      const T* kr = K + (int64_t)b * k_bs + (int64_t)j * k_rs + (int64_t)h * k_hs;
+      float s = 0.f;
+      for (int d = 0; d < hd; ++d) s = fmaf(qs[d], to_f32<T>(kr[d]), s);
+      o[j] += expf(s * scale - mx) / sum / (float)H;
+    }
+  }
+}
+template <typename T>
+void launch_attn_row_mean(const void* q, int64_t q_bs, int64_t q_hs, const void* K, int64_t k_bs, int64_t k_rs,
+                          int64_t k_hs, const int* kv_len, int B, int H, int hd, float scale, float* out,
+                          int ld_out, hipStream_t s) {
+  if (hd > 256) throw std::runtime_error("attn_row_mean: head dim > 256");
+  hipLaunchKernelGGL((attn_row_mean_kernel<T>), dim3(B), dim3(256), 0, s, reinterpret_cast<const T*>(q), q_bs,
+                     q_hs, reinterpret_cast<const T*>(K), k_bs, k_rs, k_hs, kv_len, H, hd, scale, out, ld_out);
+}
+template void launch_attn_row_mean<float>(const void*, int64_t, int64_t, const void*, int64_t, int64_t, int64_t,
+                                          const int*, int, int, int, float, float*, int, hipStream_t);
+template void launch_attn_row_mean<bf16>(const void*, int64_t, int64_t, const void*, int64_t, int64_t, int64_t,
+                                         const int*, int, int, int, float, float*, int, hipStream_t);
+
+// ---------------------------------------------------------------------------------------------
+// SAM decomposed relative-position bias tables (image_encoder.py:354-392; get_rel_pos with
+// q_size == k_size: R[q,k] = tab[q - k + size - 1]).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void rel_pos_kernel(const T* __restrict__ q, int64_t q_bs, int64_t q_rs, int64_t q_hs,
+                               const float* __restrict__ tab_h, const float* __restrict__ tab_w, int B, int H,
+                               int size, int hd, float* __restrict__ rel_h, float* __restrict__ rel_w) {
+  const int S = size * size;
+  const int64_t total = (int64_t)B * H * S * size;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(t % size);
+    const int i = (int)((t / size) % S);
+    const int h = (int)((t / ((int64_t)size * S)) % H);
+    const int b = (int)(t / ((int64_t)size * S * H));
+    const int y = i / size, x = i % size;
+    const T* qr = q + (int64_t)b * q_bs + (int64_t)i * q_rs + (int64_t)h * q_hs;
+    const float* th = tab_h + (int64_t)(y - k + size - 1) * hd;
+    const float* tw = tab_w + (int64_t)(x - k + size - 1) * hd;
+    float ah = 0.f, aw = 0.f;
+    for (int c = 0; c < hd; ++c) {
+      const float qv = to_f32<T>(qr[c]);
+      ah = fmaf(qv, th[c], ah);
+      aw = fmaf(qv, tw[c], aw);
+    }
+    rel_h[t] = ah;
+    rel_w[t] = aw;
+  }
+}
+template <typename T>
+void launch_rel_pos(const void* q, int64_t q_bs, int64_t q_rs, int64_t q_hs, const float* tab_h,
+                    const float* tab_w, int B, int H, int size, int hd, float* rel_h, float* rel_w,
+                    hipStream_t s) {
+  const int64_t total = (int64_t)B * H * size * size * size;
+  if (total <= 0) return;
+  const int grid = (int)(cdiv64(total, 256) < 65536 ? cdiv64(total, 256) : 65536);
+  hipLaunchKernelGGL((rel_pos_kernel<T>), dim3(grid), dim3(256), 0, s, reinterpret_cast<const T*>(q), q_bs, q_rs,
+                     q_hs, tab_h, tab_w, B, H, size, hd, rel_h, rel_w);
+}
+template void launch_rel_pos<float>(const void*, int64_t, int64_t, int64_t, const float*, const float*, int, int,
+                                    int, int, float*, float*, hipStream_t);
+template void launch_rel_pos<bf16>(const void*, int64_t, int64_t, int64_t, const float*, const float*, int, int,
+                                   int, int, float*, float*, hipStream_t);
+
+}  // namespace anyref

@@ -1,0 +1,112 @@
+// Shared device/host helpers for the gfx950 kernels.  Wavefront = 64 everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdexcept>
+
+namespace anyref {
+
+// ---- storage types -------------------------------------------------------------------------
+// bf16 is carried as raw 16-bit words; conversion by the hardware cvt (keeps NaN a NaN,
+// MI355X_MICROARCH "Correctness boundaries").
+struct bf16 {
+  uint16_t x;
+};
+
+__host__ __device__ inline float bf2f(bf16 h) {
+  uint32_t u = ((uint32_t)h.x) << 16;
+  return __builtin_bit_cast(float, u);
+}
+__device__ inline bf16 f2bf(float f) {
+  __bf16 h = (__bf16)f;
+  bf16 r;
+  r.x = __builtin_bit_cast(uint16_t, h);
+  return r;
+}
+inline bf16 f2bf_host(float f) {  // RNE, host side (weight packing of small tables)
+  uint32_t u = __builtin_bit_cast(uint32_t, f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) {
+    bf16 r;
+    r.x = (uint16_t)((u >> 16) | 0x40);
+    return r;
+  }
+  u += 0x7fffu + ((u >> 16) & 1u);
+  bf16 r;
+  r.x = (uint16_t)(u >> 16);
+  return r;
+}
+
+template <typename T>
+__device__ inline float to_f32(T v);
+template <>
+__device__ inline float to_f32<float>(float v) {
+  return v;
+}
+template <>
+__device__ inline float to_f32<bf16>(bf16 v) {
+  return bf2f(v);
+}
+template <typename T>
+__device__ inline T from_f32(float v);
+template <>
+__device__ inline float from_f32<float>(float v) {
+  return v;
+}
+template <>
+__device__ inline bf16 from_f32<bf16>(float v) {
+  return f2bf(v);
+}
+
+// ---- vector types --------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) short short8;   // 8 x bf16 = one MFMA A/B fragment
+typedef __attribute__((ext_vector_type(4))) float float4v;  // MFMA 16x16 accumulator
+typedef __attribute__((ext_vector_type(4))) uint32_t uint4v;
+
+// ---- activations ---------------------------------------------------------------------------
+enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_QUICK_GELU = 3, ACT_SILU = 4 };
+
+__device__ inline float apply_act(float v, int act) {
+  switch (act) {
+    case ACT_RELU:
+      return v > 0.f ? v : 0.f;
+    case ACT_GELU:  // exact erf form (torch.nn.GELU default; common.py:13-25, mask_decoder.py:53-63)
+      return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+    case ACT_QUICK_GELU:  // HF CLIP quick_gelu
+      return v / (1.f + __expf(-1.702f * v));
+    case ACT_SILU:
+      return v / (1.f + __expf(-v));
+    default:
+      return v;
+  }
+}
+
+// ---- wave reductions -----------------------------------------------------------------------
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ inline float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---- host-side error plumbing ---------------------------------------------------------------
+#define HIP_TRY(expr)                                                                   \
+  do {                                                                                  \
+    hipError_t _e = (expr);                                                             \
+    if (_e != hipSuccess) {                                                             \
+      char _b[512];                                                                     \
+      snprintf(_b, sizeof(_b), "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+               __LINE__);                                                               \
+      throw std::runtime_error(_b);                                                     \
+    }                                                                                   \
+  } while (0)
+
+__host__ __device__ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+inline int round_up(int a, int b) { return cdiv(a, b) * b; }
+
+}  // namespace anyref

@@ -1,0 +1,178 @@
+// Launcher declarations for the gfx950 kernels.  Every launcher is templated on the
+// activation/weight storage type T: `float` (parity mode, exact-f32 MFMA 16x16x4) or
+// `bf16` (perf mode, MFMA 16x16x32 bf16).  Accumulation and the residual stream are fp32 in both.
+#pragma once
+#include "common.h"
+
+namespace anyref {
+
+// C[dst(m), n] = act(alpha * sum_k A[m,k] W[n,k] + bias[n]) (+ resid[dst(m), n])
+struct GemmArgs {
+  const void* A = nullptr;  // T [M,K], row stride lda
+  const void* W = nullptr;  // T [N,K], row stride ldw  (nn.Linear layout)
+  const float* bias = nullptr;
+  void* C = nullptr;  // T or f32 [*, N], row stride ldc
+  const float* resid = nullptr;  // f32, row stride ldr, indexed by destination row; may alias C
+  const int* row_map = nullptr;  // destination row of source row m, or <0 to drop the row
+  int M = 0, N = 0, K = 0;
+  int lda = 0, ldw = 0, ldc = 0, ldr = 0;
+  int act = ACT_NONE;
+  int c_f32 = 0;  // 1: C is f32, 0: C is T
+  float alpha = 1.f;
+  // optional batching over blockIdx.z (element strides)
+  int batch = 1;
+  int64_t sA = 0, sW = 0, sC = 0, sR = 0, sBias = 0;
+};
+template <typename T>
+void launch_gemm(const GemmArgs& a, hipStream_t s);
+
+// Small-M weight-streaming GEMV for the decode step (HBM-bound):
+// y[b, n] = act(sum_k xn[b,k] W[n,k]) (+ resid) where xn = rmsnorm(x) * gain if gain != null.
+struct GemvArgs {
+  const float* x = nullptr;  // f32 [B,K] (residual stream / activations), row stride ldx
+  const float* gain = nullptr;  // RMSNorm weight [K] or null (no norm)
+  float eps = 1e-6f;
+  const void* W = nullptr;   // T [N,K]
+  const void* W2 = nullptr;  // T [N,K] or null; if set: y = silu(x.W) * (x.W2)  (SwiGLU)
+  const float* bias = nullptr;
+  float* y = nullptr;  // f32 [B,N], row stride ldy
+  const float* resid = nullptr;  // f32 [B,N] row stride ldy, may alias y
+  int B = 1, N = 0, K = 0, ldx = 0, ldy = 0;
+  int act = ACT_NONE;
+};
+template <typename T>
+void launch_gemv(const GemvArgs& a, hipStream_t s);
+
+// y[dst(m)] = LN(x[m]) * g + b   (rms: y = x * rsqrt(mean x^2 + eps) * g)
+struct NormArgs {
+  const float* x = nullptr;  // f32 [M,D], row stride ldx
+  const float* gain = nullptr;
+  const float* bias = nullptr;  // null for RMSNorm
+  void* y = nullptr;            // T or f32, row stride ldy
+  const int* row_map = nullptr;
+  int M = 0, D = 0, ldx = 0, ldy = 0;
+  float eps = 1e-5f;
+  int rms = 0;
+  int y_f32 = 0;
+  int act = ACT_NONE;  // applied after the affine (LayerNorm2d -> GELU in the upscaler)
+};
+template <typename T>
+void launch_norm(const NormArgs& a, hipStream_t s);
+
+// Fused multi-head attention, online softmax.  Element strides; Q/K/V/O are T.
+// score(i,j) = scale * q_i.k_j + rel_h[i, j / kw] + rel_w[i, j % kw]; key j visible iff
+// j < kv_len[b] and (!causal or j <= q_pos0[b] + i).
+struct AttnArgs {
+  const void *Q = nullptr, *K = nullptr, *V = nullptr;
+  void* O = nullptr;
+  int64_t q_bs = 0, q_rs = 0, q_hs = 0;  // batch / row / head strides
+  int64_t k_bs = 0, k_rs = 0, k_hs = 0;
+  int64_t v_bs = 0, v_rs = 0, v_hs = 0;
+  int64_t o_bs = 0, o_rs = 0, o_hs = 0;
+  int B = 0, H = 0, Sq = 0, Sk = 0, hd = 0;
+  float scale = 1.f;
+  int causal = 0;
+  const int* q_pos0 = nullptr;  // [B] position of query row 0 (causal with a KV cache); null = 0
+  const int* kv_len = nullptr;  // [B] or null (= Sk)
+  const int* q_len = nullptr;   // [B] or null (= Sq): rows >= q_len are skipped
+  const float* rel_h = nullptr;  // f32 [B,H,Sq,kh] or null
+  const float* rel_w = nullptr;  // f32 [B,H,Sq,kw]
+  int kh = 0, kw = 0;
+  int o_f32 = 0;  // 1: O is f32 instead of T (decode step feeds the f32 GEMV)
+};
+template <typename T>
+void launch_attention(const AttnArgs& a, hipStream_t s);
+
+// Head-mean softmax row of ONE query per batch element over keys [0, kv_len):
+// out[b, j] = mean_h softmax_j(scale * q[b,h].k[b,j,h])   (anyref.py:748-749)
+template <typename T>
+void launch_attn_row_mean(const void* q, int64_t q_bs, int64_t q_hs, const void* K, int64_t k_bs,
+                          int64_t k_rs, int64_t k_hs, const int* kv_len, int B, int H, int hd,
+                          float scale, float* out, int ld_out, hipStream_t s);
+
+// ---- SAM decomposed rel-pos bias (image_encoder.py:354-392) -------------------------------
+// rel_h[b,h,(y,x),ky] = sum_c q[b,(y,x),h,c] * tab_h[y - ky + size-1, c]; likewise rel_w with x.
+template <typename T>
+void launch_rel_pos(const void* q, int64_t q_bs, int64_t q_rs, int64_t q_hs, const float* tab_h,
+                    const float* tab_w, int B, int H, int size, int hd, float* rel_h, float* rel_w,
+                    hipStream_t s);
+
+// ---- data movement / elementwise ------------------------------------------------------------
+// non-overlapping patch im2col: img f32 [B,3,S,S] -> out T [B*g*g, Kp], k = c*p*p + ky*p + kx
+template <typename T>
+void launch_im2col_patch(const float* img, int B, int S, int p, void* out, int Kp, hipStream_t s);
+// 3x3 pad-1 im2col on NHWC tokens: in T [B,g,g,C] -> out T [B*g*g, 9*C], k = (ky*3+kx)*C + c
+template <typename T>
+void launch_im2col_3x3(const void* in, int B, int g, int C, void* out, hipStream_t s);
+// generic f32 -> T convert / copy with strides (rows x cols)
+template <typename T>
+void launch_convert(const float* in, int64_t ld_in, void* out, int64_t ld_out, int rows, int cols,
+                    hipStream_t s);
+// out[m, :] = a[m, :] + b[m % bmod, :]   (f32; position embeddings, keys+pe ...)
+void launch_add_rows(const float* a, const float* b, int bmod, float* out, int M, int D, hipStream_t s);
+template <typename T>
+void launch_add_rows_to(const float* a, const float* b, int bmod, void* out, int M, int D, hipStream_t s);
+// CLIP embeddings: x[b,0]=cls+pos[0]; x[b,1+i]=patch[b,i]+pos[1+i]   (f32)
+void launch_clip_assemble(const float* patch, const float* cls, const float* pos, float* x, int B, int n,
+                          int D, hipStream_t s);
+// token embedding gather + multimodal splice (LLaVA prepare_inputs; see oracle.splice_embeddings)
+// ids i64 dev [B,Lmax], lens i32 dev [B]; image placeholder (-200) expands to n_img rows of img_feat[b].
+// extra rows replace 1:1.  x f32 [B,Smax,D]; out_len i32 dev [B] (= len + n_img - 1 when an image is present).
+void launch_embed_splice(const int64_t* ids, const int* lens, int B, int Lmax, const void* emb_table,
+                         int emb_is_bf16, int vocab, const float* img_feat, int n_img, float* x, int Smax,
+                         int D, int* out_len, hipStream_t s);
+void launch_scatter_rows(const float* rows, const int* dst_b, const int* dst_pos, int n, float* x, int Smax,
+                         int D, hipStream_t s);
+// RoPE (rotate_half form) on q,k of a fused qkv buffer + append k,v to the cache.
+// qkv T [B,S,3,H,hd]; pos0 i32 [B] dev; q_out T [B,S,H,hd]; kc/vc T [B,maxS,H,hd];
+// cs_tab f32 [maxS][2][hd/2] = cos | sin of pos * inv_freq (built on the host like HF does)
+template <typename T>
+void launch_rope_cache(const void* qkv, int B, int S, int H, int hd, const int* pos0, const int* lens,
+                       const float* cs_tab, void* q_out, void* kc, void* vc, int maxS, void* q_keep,
+                       hipStream_t s);
+// same from an f32 qkv row buffer [B,3*H*hd] (decode step)
+// q_keep (optional): rotated q also stored at [b, pos] of a [B,maxS,H,hd] buffer (rephrase branch)
+template <typename T>
+void launch_rope_cache_f32(const float* qkv, int B, int H, int hd, const int* pos, const float* cs_tab,
+                           void* q_out, void* kc, void* vc, int maxS, void* q_keep, hipStream_t s);
+// token embedding rows for the decode step: x[b,:] = table[ids[b],:]
+void launch_embed_rows(const int64_t* ids, int B, const void* table, int is_bf16, int D, float* x, hipStream_t s);
+// row_map[b] = b*maxS + pos[b]; kvlen[b] = pos[b] + 1
+void launch_decode_index(const int* pos, int B, int maxS, int* row_map, int* kvlen, hipStream_t s);
+// tokens[i, 0:n_out] = out_tokens; tokens[i, n_out] = pred[i]   (mask_decoder.py:127-141)
+void launch_build_tokens(const float* out_tokens, int n_out, const float* pred, int n, int C, float* tokens,
+                         hipStream_t s);
+// act[m, j] = silu(gu[m, j]) * gu[m, F + j]
+template <typename T>
+void launch_swiglu(const void* gu, int M, int F, void* out, hipStream_t s);
+// argmax over f32 rows (first index on ties) -> i64
+void launch_argmax(const float* x, int M, int N, int ldx, int64_t* out, hipStream_t s);
+// ConvTranspose2d k2s2 output un-shuffle (+ LayerNorm2d + GELU): tmp f32 [n*g*g, 4*C] (col = (dy*2+dx)*C+c)
+// -> out T [n*(2g)*(2g), C] NHWC
+template <typename T>
+void launch_upscale1(const float* tmp, int n, int g, int C, const float* ln_g, const float* ln_b, float eps,
+                     void* out, hipStream_t s);
+// second ConvT un-shuffle + GELU + hypernetwork product:
+// masks[i,t,Y,X] = sum_c hyper[i,t,c] * gelu(tmp[i,(Y/2,X/2),(Y%2*2+X%2)*C + c])
+void launch_upscale2_masks(const float* tmp, const float* hyper, int n, int ntok, int g2, int C, float* masks,
+                           hipStream_t s);
+// Sam.postprocess_masks (sam.py:137-172): two chained bilinear resizes (align_corners=False) + crop.
+// low f32 [n, lh, lw] (lstride between masks) -> out [n, H, W]
+void launch_postprocess(const float* low, int64_t lstride, int n, int lh, int lw, int S, int rh, int rw, int H,
+                        int W, float* out, hipStream_t s);
+// dense PE table (prompt_encoder.py:189-229): out f32 [g*g, 2*F], gauss f32 [2,F]
+void launch_dense_pe(const float* gauss, int g, int F, float* out, hipStream_t s);
+void launch_fill_i32(int* p, int v, int n, hipStream_t s);
+void launch_add_i32(int* p, int v, int n, hipStream_t s);
+// per-row broadcast add: out[m,:] = a[m,:] + v[:]  (f32)
+void launch_add_vec(const float* a, const float* v, float* out, int M, int D, hipStream_t s);
+// gather rows: out[i,:] = x[b[i], pos[i], :]
+void launch_gather_rows(const float* x, int Smax, int D, const int* b, const int* pos, int n, float* out,
+                        hipStream_t s);
+// y += w * sum_j p[j] * X[j,:]  with p normalised to sum 1 over [s,e)   (rephrase, anyref.py:746-755)
+void launch_rephrase(const float* hidden_b, int D, const float* attn_row, int s0, int e0, float weight,
+                     float* y, hipStream_t s);
+// convert generic dtype weight to f32 (dtype codes of anyref_hip.h)
+void launch_to_f32(const void* in, int dtype, float* out, int64_t n, hipStream_t s);
+
+}  // namespace anyref

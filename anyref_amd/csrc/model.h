@@ -1,0 +1,75 @@
+// Host-side model: weight store, packed weights, workspaces, stage orchestration.
+#pragma once
+#include <map>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/anyref_hip.h"
+#include "kernels.h"
+
+namespace anyref {
+
+struct RawTensor {
+  float* p = nullptr;  // f32 device copy
+  std::vector<int64_t> shape;
+  int64_t numel() const {
+    int64_t n = 1;
+    for (auto s : shape) n *= s;
+    return n;
+  }
+};
+
+// Mode-independent interface behind the C-ABI.
+class ModelBase {
+ public:
+  explicit ModelBase(const anyref_config& c, int device);
+  virtual ~ModelBase();
+
+  void set_weight(const char* name, const void* ptr, int is_device, int dtype, const int64_t* shape, int ndim);
+  virtual void finalize() = 0;
+  virtual const char* mode_name() const = 0;
+
+  virtual void generate(hipStream_t s, const float* clip_images, const float* sam_images, const int64_t* input_ids,
+                        const int32_t* lens, int B, int Lmax, const float* extra_embeds,
+                        const int32_t* extra_slots, int n_extra, const int32_t* resized_hw, const int32_t* orig_hw,
+                        int max_new_tokens, int eos_token_id, int64_t* out_ids, int32_t* out_lens,
+                        int32_t* out_nseg, float* out_masks, int64_t out_masks_cap, int64_t* mask_offsets,
+                        float* out_low, float* out_hidden) = 0;
+  virtual void forward_teacher(hipStream_t s, const float* clip_images, const float* sam_images,
+                               const int64_t* input_ids, const int32_t* lens, int B, int Lmax,
+                               const float* extra_embeds, const int32_t* extra_slots, int n_extra,
+                               const int32_t* rephrase_start, const int32_t* resized_hw, const int32_t* orig_hw,
+                               int32_t* out_nseg, float* out_masks, int64_t out_masks_cap, int64_t* mask_offsets,
+                               float* out_low, float* out_hidden, float* out_logits) = 0;
+  virtual void encode_images(hipStream_t s, const float* clip_images, int B, float* out, float* clip_feat) = 0;
+  virtual void sam_encode(hipStream_t s, const float* sam_images, int B, float* out) = 0;
+  virtual void mask_decode(hipStream_t s, const float* image_emb, const float* pred_emb, int n, float* masks4,
+                           float* iou, const int32_t* resized_hw, const int32_t* orig_hw, float* out_masks) = 0;
+  virtual void llm_forward(hipStream_t s, const float* embeds, const int32_t* lens, int B, int S, float* hidden,
+                           float* logits, const int32_t* attn_q, float* attn_row) = 0;
+  virtual void project_audio(hipStream_t s, const float* audio_emb, int n, float* out) = 0;
+
+  int64_t device_bytes() const { return bytes_; }
+  std::string err;
+  int n_unknown = 0;
+
+ protected:
+  void* dalloc(size_t bytes);  // tracked hipMalloc (freed in the destructor)
+  void dfree(void* p);
+  const RawTensor& raw(const std::string& name) const;
+  bool has_raw(const std::string& name) const { return raw_.count(name) != 0; }
+  void drop_raw();
+
+  anyref_config cfg;
+  int device_;
+  int64_t bytes_ = 0;
+  std::unordered_map<void*, size_t> allocs_;
+  std::map<std::string, RawTensor> raw_;
+  bool finalized_ = false;
+};
+
+std::unique_ptr<ModelBase> make_model(const anyref_config& cfg, int device);
+
+}  // namespace anyref

@@ -1,0 +1,1285 @@
+// Stage orchestration of the AnyRef inference path on one MI355X.
+//
+//   encode_images : CLIP ViT tower (hidden_states[-2], CLS dropped) -> mm_projector      (anyref.py:334)
+//   llm           : LLaVA splice -> LLaMA prefill -> greedy decode with a KV cache        (anyref.py:704-718)
+//   handoff       : [SEG] hidden state (+ rephrase) -> text_hidden_fcs                    (anyref.py:723-770)
+//   sam_encode    : ImageEncoderViT (windowed / global attention + rel-pos) + neck       (image_encoder.py)
+//   mask_decode   : prompt encoder (text) + two-way transformer + upscaler + postprocess  (anyref.py:797-819)
+//
+// Template parameter T is the storage type of the big operands: float (parity mode) or bf16
+// (perf mode).  The residual streams, every accumulation, the [SEG] hand-off and the whole mask
+// decoder are fp32 in both modes (the decoder is 3.6 GFLOP: running it on the f32 MFMA costs
+// microseconds and removes its bf16 error from the logits).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "model.h"
+
+namespace anyref {
+
+// =============================================================================================
+// ModelBase
+// =============================================================================================
+ModelBase::ModelBase(const anyref_config& c, int device) : cfg(c), device_(device) { HIP_TRY(hipSetDevice(device)); }
+
+ModelBase::~ModelBase() {
+  (void)hipSetDevice(device_);
+  (void)hipDeviceSynchronize();
+  for (auto& kv : allocs_) (void)hipFree(kv.first);
+}
+
+void* ModelBase::dalloc(size_t bytes) {
+  if (bytes == 0) bytes = 16;
+  void* p = nullptr;
+  HIP_TRY(hipMalloc(&p, bytes));
+  allocs_[p] = bytes;
+  bytes_ += (int64_t)bytes;
+  return p;
+}
+void ModelBase::dfree(void* p) {
+  auto it = allocs_.find(p);
+  if (it == allocs_.end()) return;
+  bytes_ -= (int64_t)it->second;
+  (void)hipFree(p);
+  allocs_.erase(it);
+}
+
+void ModelBase::set_weight(const char* name, const void* ptr, int is_device, int dtype, const int64_t* shape,
+                           int ndim) {
+  HIP_TRY(hipSetDevice(device_));
+  if (finalized_) throw std::runtime_error("set_weight after finalize");
+  RawTensor t;
+  t.shape.assign(shape, shape + ndim);
+  const int64_t n = t.numel();
+  const size_t esz = dtype == ANYREF_F32 ? 4 : 2;
+  if (dtype != ANYREF_F32 && dtype != ANYREF_BF16 && dtype != ANYREF_F16) throw std::runtime_error("bad dtype");
+  auto it = raw_.find(name);
+  if (it != raw_.end()) {
+    dfree(it->second.p);
+    raw_.erase(it);
+  }
+  t.p = (float*)dalloc((size_t)n * 4);
+  const void* src = ptr;
+  void* staged = nullptr;
+  if (!is_device) {
+    if (dtype == ANYREF_F32) {
+      HIP_TRY(hipMemcpy(t.p, ptr, (size_t)n * 4, hipMemcpyHostToDevice));
+      raw_[name] = t;
+      return;
+    }
+    HIP_TRY(hipMalloc(&staged, (size_t)n * esz));
+    HIP_TRY(hipMemcpy(staged, ptr, (size_t)n * esz, hipMemcpyHostToDevice));
+    src = staged;
+  }
+  launch_to_f32(src, dtype, t.p, n, 0);
+  HIP_TRY(hipStreamSynchronize(0));
+  if (staged) (void)hipFree(staged);
+  raw_[name] = t;
+}
+
+const RawTensor& ModelBase::raw(const std::string& name) const {
+  auto it = raw_.find(name);
+  if (it == raw_.end()) throw std::runtime_error("missing weight: " + name);
+  return it->second;
+}
+void ModelBase::drop_raw() {
+  for (auto& kv : raw_)
+    if (kv.second.p) dfree(kv.second.p);
+  raw_.clear();
+}
+
+// =============================================================================================
+// Model<T>
+// =============================================================================================
+template <typename T>
+struct Lin {  // nn.Linear packed in T
+  T* w = nullptr;
+  float* b = nullptr;
+  int n = 0, k = 0;  // k = padded row length
+};
+struct LinF {  // nn.Linear kept in f32
+  float* w = nullptr;
+  float* b = nullptr;
+  int n = 0, k = 0;
+};
+struct Affine {
+  float* g = nullptr;
+  float* b = nullptr;
+};
+
+template <typename T>
+class Model : public ModelBase {
+ public:
+  Model(const anyref_config& c, int device) : ModelBase(c, device) {}
+  const char* mode_name() const override { return sizeof(T) == 2 ? "bf16" : "f32"; }
+  void finalize() override;
+  void generate(hipStream_t s, const float* clip_images, const float* sam_images, const int64_t* input_ids,
+                const int32_t* lens, int B, int Lmax, const float* extra_embeds, const int32_t* extra_slots,
+                int n_extra, const int32_t* resized_hw, const int32_t* orig_hw, int max_new_tokens,
+                int eos_token_id, int64_t* out_ids, int32_t* out_lens, int32_t* out_nseg, float* out_masks,
+                int64_t out_masks_cap, int64_t* mask_offsets, float* out_low, float* out_hidden) override;
+  void forward_teacher(hipStream_t s, const float* clip_images, const float* sam_images, const int64_t* input_ids,
+                       const int32_t* lens, int B, int Lmax, const float* extra_embeds, const int32_t* extra_slots,
+                       int n_extra, const int32_t* rephrase_start, const int32_t* resized_hw,
+                       const int32_t* orig_hw, int32_t* out_nseg, float* out_masks, int64_t out_masks_cap,
+                       int64_t* mask_offsets, float* out_low, float* out_hidden, float* out_logits) override;
+  void encode_images(hipStream_t s, const float* clip_images, int B, float* out, float* clip_feat) override;
+  void sam_encode(hipStream_t s, const float* sam_images, int B, float* out) override;
+  void mask_decode(hipStream_t s, const float* image_emb, const float* pred_emb, int n, float* masks4, float* iou,
+                   const int32_t* resized_hw, const int32_t* orig_hw, float* out_masks) override;
+  void llm_forward(hipStream_t s, const float* embeds, const int32_t* lens, int B, int S, float* hidden,
+                   float* logits, const int32_t* attn_q, float* attn_row) override;
+  void project_audio(hipStream_t s, const float* audio_emb, int n, float* out) override;
+
+ private:
+  // ---- packing helpers ----
+  float* own_f32(const std::string& name);  // take the raw f32 copy as is
+  float* upload_f32(const std::vector<float>& v);
+  std::vector<float> to_host(const std::string& name);
+  T* pack_rows(T* dst, int dst_row0, const std::string& name, int rows, int cols, int kpad);
+  Lin<T> pack_linear(const std::string& wname, const std::string& bname, int n, int k);
+  LinF pack_linear_f32(const std::string& wname, const std::string& bname, int n, int k);
+  Affine affine(const std::string& prefix, bool bias = true);
+  template <typename U>
+  U* talloc(size_t n) {
+    return reinterpret_cast<U*>(dalloc(n * sizeof(U)));
+  }
+
+  // ---- op helpers ----
+  void gemm(hipStream_t s, const T* A, int lda, const Lin<T>& l, void* C, int ldc, int M, int act, bool c_f32,
+            const float* resid = nullptr, int ldr = 0, const int* row_map = nullptr) {
+    GemmArgs a;
+    a.A = A; a.lda = lda; a.W = l.w; a.ldw = l.k; a.bias = l.b; a.C = C; a.ldc = ldc; a.M = M; a.N = l.n;
+    a.K = l.k; a.act = act; a.c_f32 = c_f32 ? 1 : 0; a.resid = resid; a.ldr = ldr; a.row_map = row_map;
+    launch_gemm<T>(a, s);
+  }
+  void gemmf(hipStream_t s, const float* A, int lda, const LinF& l, float* C, int ldc, int M, int act,
+             const float* resid = nullptr, int ldr = 0) {
+    GemmArgs a;
+    a.A = A; a.lda = lda; a.W = l.w; a.ldw = l.k; a.bias = l.b; a.C = C; a.ldc = ldc; a.M = M; a.N = l.n;
+    a.K = l.k; a.act = act; a.c_f32 = 1; a.resid = resid; a.ldr = ldr;
+    launch_gemm<float>(a, s);
+  }
+  void norm(hipStream_t s, const float* x, int ldx, const Affine& af, void* y, int ldy, int M, int D, float eps,
+            bool y_f32, bool rms = false, const int* row_map = nullptr, int act = ACT_NONE) {
+    NormArgs a;
+    a.x = x; a.ldx = ldx; a.gain = af.g; a.bias = af.b; a.y = y; a.ldy = ldy; a.M = M; a.D = D; a.eps = eps;
+    a.rms = rms ? 1 : 0; a.y_f32 = y_f32 ? 1 : 0; a.row_map = row_map; a.act = act;
+    launch_norm<T>(a, s);
+  }
+
+  // ---- stages ----
+  void clip_tower(hipStream_t s, const float* images, int B);  // -> img_feat_ [B,n,H]
+  void llm_prefill(hipStream_t s, int B, int Sp, const int* lens_dev, bool keep_q);
+  void llm_decode_step(hipStream_t s, int B, bool keep_q);
+  void sam_encoder(hipStream_t s, const float* images, int B, float* out);
+  void mask_decoder(hipStream_t s, const float* image_emb, const float* pred_emb, int n, float* masks4,
+                    float* iou);
+  void run_tail(hipStream_t s, const float* sam_images, int B, const std::vector<int>& seg_b,
+                const std::vector<int>& seg_pos, const std::vector<int>& reph_s, const int32_t* resized_hw,
+                const int32_t* orig_hw, int32_t* out_nseg, float* out_masks, int64_t out_masks_cap,
+                int64_t* mask_offsets, float* out_low);
+  int splice_inputs(hipStream_t s, const int64_t* input_ids, const int32_t* lens, int B, int Lmax,
+                    const float* extra_embeds, const int32_t* extra_slots, int n_extra,
+                    std::vector<int>& slen, std::vector<int>& img_pos);
+  void ensure_q_last();
+
+  // ---- CLIP ----
+  struct ClipLayer {
+    Affine ln1, ln2;
+    Lin<T> qkv, out, fc1, fc2;
+  };
+  int clip_n_ = 0, clip_kp_ = 0;
+  Lin<T> clip_patch_;
+  float *clip_cls_ = nullptr, *clip_pos_ = nullptr;
+  Affine clip_pre_;
+  std::vector<ClipLayer> clip_layers_;
+  Lin<T> mm_proj_;
+  T *c_col_ = nullptr, *c_h_ = nullptr, *c_qkv_ = nullptr, *c_att_ = nullptr, *c_mlp_ = nullptr, *c_feat_ = nullptr;
+  float *c_patch_ = nullptr, *c_x_ = nullptr, *img_feat_ = nullptr;
+
+  // ---- LLM ----
+  struct LlmLayer {
+    Affine in_norm, post_norm;
+    Lin<T> qkv, o, gu, down;
+    T *gate_w = nullptr, *up_w = nullptr;  // views into gu.w
+  };
+  T* emb_table_ = nullptr;
+  std::vector<LlmLayer> llm_layers_;
+  Affine llm_norm_;
+  Lin<T> lm_head_;
+  float* rope_tab_ = nullptr;
+  T *kcache_ = nullptr, *vcache_ = nullptr, *q_last_ = nullptr;
+  size_t cache_layer_stride_ = 0;
+  float *l_x_ = nullptr, *hidden_all_ = nullptr, *l_logits_ = nullptr, *l_xlast_ = nullptr;
+  T *l_h_ = nullptr, *l_qkv_ = nullptr, *l_q_ = nullptr, *l_att_ = nullptr, *l_gu_ = nullptr, *l_act_ = nullptr;
+  float *d_x_ = nullptr, *d_qkv_ = nullptr, *d_att_ = nullptr, *d_act_ = nullptr;
+  T* d_q_ = nullptr;
+  int64_t *ids_dev_ = nullptr, *next_dev_ = nullptr;
+  int *lens_dev_ = nullptr, *slen_dev_ = nullptr, *pos_dev_ = nullptr, *kvlen_dev_ = nullptr, *rowmap_dev_ = nullptr,
+      *idx_a_ = nullptr, *idx_b_ = nullptr;
+  int64_t* next_host_ = nullptr;  // pinned
+
+  // ---- glue ----
+  LinF fc1_, fc2_;
+  Lin<T> audio_proj_;
+  bool has_audio_ = false;
+  float *seg_h_ = nullptr, *seg_t_ = nullptr, *pred_emb_ = nullptr, *attn_row_ = nullptr;
+
+  // ---- SAM encoder ----
+  struct SamBlock {
+    Affine ln1, ln2;
+    Lin<T> qkv, proj, lin1, lin2;
+    float *rel_h = nullptr, *rel_w = nullptr;
+    bool global = false;
+  };
+  Lin<T> sam_patch_;
+  float* sam_pos_ = nullptr;
+  std::vector<SamBlock> sam_blocks_;
+  Lin<T> neck0_, neck2_;
+  Affine neck1_, neck3_;
+  int sam_g_ = 0, sam_nw_ = 0, sam_wrows_ = 0;  // grid, windows per side, window-layout rows per image
+  int *win2tok_ = nullptr, *tok2win_ = nullptr;
+  T *s_col_ = nullptr, *s_hwin_ = nullptr, *s_hglob_ = nullptr, *s_qkv_ = nullptr, *s_att_ = nullptr,
+    *s_mlp_ = nullptr, *s_n1_ = nullptr, *s_col3_ = nullptr;
+  float *s_x_ = nullptr, *s_relh_ = nullptr, *s_relw_ = nullptr, *s_n0_ = nullptr, *s_n2_ = nullptr,
+        *sam_emb_ = nullptr;
+
+  // ---- prompt encoder + mask decoder (f32) ----
+  struct DecAttn {
+    LinF q, k, v, o;
+  };
+  struct DecLayer {
+    DecAttn self, t2i, i2t;
+    Affine n1, n2, n3, n4;
+    LinF lin1, lin2;
+  };
+  float *dense_pe_ = nullptr, *no_mask_ = nullptr, *out_tokens_ = nullptr;
+  std::vector<DecLayer> dec_layers_;
+  DecAttn dec_final_;
+  Affine dec_norm_final_, up_ln_;
+  LinF up1_, up2_;
+  LinF hyper_[3], iou_head_[3];  // hyper: stacked over the mask tokens
+  float *m_tokens_ = nullptr, *m_q_ = nullptr, *m_qp_ = nullptr, *m_keys_ = nullptr, *m_kp_ = nullptr,
+        *m_qh_ = nullptr, *m_kh_ = nullptr, *m_vh_ = nullptr, *m_att_ = nullptr, *m_tmp_ = nullptr, *m_mlp_ = nullptr,
+        *m_bigq_ = nullptr, *m_bigk_ = nullptr, *m_bigv_ = nullptr, *m_bigatt_ = nullptr, *m_up0_ = nullptr,
+        *m_up1_ = nullptr, *m_up2_ = nullptr, *m_hy0_ = nullptr, *m_hy1_ = nullptr, *m_hyper_ = nullptr,
+        *m_masks_ = nullptr, *m_iou_ = nullptr, *m_src_ = nullptr;
+};
+
+// ---------------------------------------------------------------------------------------------
+// packing
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+float* Model<T>::own_f32(const std::string& name) {
+  auto it = raw_.find(name);
+  if (it == raw_.end()) throw std::runtime_error("missing weight: " + name);
+  float* p = it->second.p;
+  it->second.p = nullptr;  // ownership moves to the packed model (still tracked in allocs_)
+  return p;
+}
+template <typename T>
+std::vector<float> Model<T>::to_host(const std::string& name) {
+  const RawTensor& t = raw(name);
+  std::vector<float> v((size_t)t.numel());
+  HIP_TRY(hipMemcpy(v.data(), t.p, v.size() * 4, hipMemcpyDeviceToHost));
+  return v;
+}
+template <typename T>
+float* Model<T>::upload_f32(const std::vector<float>& v) {
+  float* p = talloc<float>(v.size());
+  HIP_TRY(hipMemcpy(p, v.data(), v.size() * 4, hipMemcpyHostToDevice));
+  return p;
+}
+template <typename T>
+T* Model<T>::pack_rows(T* dst, int dst_row0, const std::string& name, int rows, int cols, int kpad) {
+  const RawTensor& t = raw(name);
+  if (t.numel() != (int64_t)rows * cols)
+    throw std::runtime_error("shape mismatch for " + name + ": expected " + std::to_string(rows) + "x" +
+                             std::to_string(cols) + ", got " + std::to_string(t.numel()) + " elements");
+  launch_convert<T>(t.p, cols, dst + (int64_t)dst_row0 * kpad, kpad, rows, cols, 0);
+  return dst;
+}
+template <typename T>
+Lin<T> Model<T>::pack_linear(const std::string& wname, const std::string& bname, int n, int k) {
+  Lin<T> l;
+  l.n = n;
+  l.k = round_up(k, 8);
+  l.w = talloc<T>((size_t)n * l.k);
+  if (l.k != k) HIP_TRY(hipMemset(l.w, 0, (size_t)n * l.k * sizeof(T)));
+  pack_rows(l.w, 0, wname, n, k, l.k);
+  if (!bname.empty()) {
+    if (raw(bname).numel() != n) throw std::runtime_error("bias shape mismatch for " + bname);
+    l.b = own_f32(bname);
+  }
+  return l;
+}
+template <typename T>
+LinF Model<T>::pack_linear_f32(const std::string& wname, const std::string& bname, int n, int k) {
+  LinF l;
+  l.n = n;
+  l.k = k;
+  if (raw(wname).numel() != (int64_t)n * k) throw std::runtime_error("shape mismatch for " + wname);
+  if (k % 4) throw std::runtime_error("f32 linear needs K % 4 == 0: " + wname);
+  l.w = own_f32(wname);
+  if (!bname.empty()) l.b = own_f32(bname);
+  return l;
+}
+template <typename T>
+Affine Model<T>::affine(const std::string& prefix, bool bias) {
+  Affine a;
+  a.g = own_f32(prefix + ".weight");
+  if (bias) a.b = own_f32(prefix + ".bias");
+  return a;
+}
+
+static const char* CLIP_P = "model.vision_tower.vision_tower.vision_model.";
+static const char* SAM_P = "model.visual_model.";
+
+template <typename T>
+void Model<T>::finalize() {
+  HIP_TRY(hipSetDevice(device_));
+  if (finalized_) return;
+  const anyref_config& c = cfg;
+  const int MB = c.max_batch;
+  // ================= CLIP =================
+  {
+    const std::string p = CLIP_P;
+    const int Dc = c.clip_dim, g = c.clip_image / c.clip_patch;
+    clip_n_ = g * g;
+    const int K = 3 * c.clip_patch * c.clip_patch;
+    clip_patch_ = pack_linear(p + "embeddings.patch_embedding.weight", "", Dc, K);
+    clip_kp_ = clip_patch_.k;
+    clip_cls_ = own_f32(p + "embeddings.class_embedding");
+    clip_pos_ = own_f32(p + "embeddings.position_embedding.weight");
+    clip_pre_ = affine(p + "pre_layrnorm");
+    clip_layers_.resize(c.clip_layers_run);
+    for (int i = 0; i < c.clip_layers_run; ++i) {
+      const std::string lp = p + "encoder.layers." + std::to_string(i) + ".";
+      ClipLayer& L = clip_layers_[i];
+      L.ln1 = affine(lp + "layer_norm1");
+      L.ln2 = affine(lp + "layer_norm2");
+      L.qkv.n = 3 * Dc;
+      L.qkv.k = Dc;
+      L.qkv.w = talloc<T>((size_t)3 * Dc * Dc);
+      L.qkv.b = talloc<float>(3 * Dc);
+      const char* names[3] = {"q_proj", "k_proj", "v_proj"};
+      for (int j = 0; j < 3; ++j) {
+        pack_rows(L.qkv.w, j * Dc, lp + "self_attn." + names[j] + ".weight", Dc, Dc, Dc);
+        HIP_TRY(hipMemcpy(L.qkv.b + j * Dc, raw(lp + "self_attn." + names[j] + ".bias").p, Dc * 4,
+                          hipMemcpyDeviceToDevice));
+      }
+      L.out = pack_linear(lp + "self_attn.out_proj.weight", lp + "self_attn.out_proj.bias", Dc, Dc);
+      L.fc1 = pack_linear(lp + "mlp.fc1.weight", lp + "mlp.fc1.bias", c.clip_mlp, Dc);
+      L.fc2 = pack_linear(lp + "mlp.fc2.weight", lp + "mlp.fc2.bias", Dc, c.clip_mlp);
+    }
+    mm_proj_ = pack_linear("model.mm_projector.weight", "model.mm_projector.bias", c.llm_dim, Dc);
+    const size_t R = (size_t)MB * (clip_n_ + 1);
+    c_col_ = talloc<T>((size_t)MB * clip_n_ * clip_kp_);
+    c_patch_ = talloc<float>((size_t)MB * clip_n_ * Dc);
+    c_x_ = talloc<float>(R * Dc);
+    c_h_ = talloc<T>(R * Dc);
+    c_qkv_ = talloc<T>(R * 3 * Dc);
+    c_att_ = talloc<T>(R * Dc);
+    c_mlp_ = talloc<T>(R * c.clip_mlp);
+    c_feat_ = talloc<T>((size_t)MB * clip_n_ * Dc);
+    img_feat_ = talloc<float>((size_t)MB * clip_n_ * c.llm_dim);
+  }
+  // ================= LLaMA =================
+  {
+    const int H = c.llm_dim, F = c.llm_mlp, V = c.llm_vocab, S = c.llm_max_seq, nh = c.llm_heads, hd = H / nh;
+    if (raw("model.embed_tokens.weight").numel() != (int64_t)V * H)
+      throw std::runtime_error("embed_tokens shape mismatch (vocab/dim)");
+    emb_table_ = talloc<T>((size_t)V * H);
+    pack_rows(emb_table_, 0, "model.embed_tokens.weight", V, H, H);
+    llm_layers_.resize(c.llm_layers);
+    for (int i = 0; i < c.llm_layers; ++i) {
+      const std::string lp = "model.layers." + std::to_string(i) + ".";
+      LlmLayer& L = llm_layers_[i];
+      L.in_norm = affine(lp + "input_layernorm", false);
+      L.post_norm = affine(lp + "post_attention_layernorm", false);
+      L.qkv.n = 3 * H;
+      L.qkv.k = H;
+      L.qkv.w = talloc<T>((size_t)3 * H * H);
+      const char* names[3] = {"q_proj", "k_proj", "v_proj"};
+      for (int j = 0; j < 3; ++j) pack_rows(L.qkv.w, j * H, lp + "self_attn." + names[j] + ".weight", H, H, H);
+      L.o = pack_linear(lp + "self_attn.o_proj.weight", "", H, H);
+      L.gu.n = 2 * F;
+      L.gu.k = H;
+      L.gu.w = talloc<T>((size_t)2 * F * H);
+      pack_rows(L.gu.w, 0, lp + "mlp.gate_proj.weight", F, H, H);
+      pack_rows(L.gu.w, F, lp + "mlp.up_proj.weight", F, H, H);
+      L.gate_w = L.gu.w;
+      L.up_w = L.gu.w + (size_t)F * H;
+      L.down = pack_linear(lp + "mlp.down_proj.weight", "", H, F);
+      if (L.down.k != F) throw std::runtime_error("llm_mlp must be a multiple of 8");
+      // free the raw copies of this layer early (7B in f32 is 27 GB)
+      HIP_TRY(hipStreamSynchronize(0));
+      for (const char* nm : {"self_attn.q_proj.weight", "self_attn.k_proj.weight", "self_attn.v_proj.weight",
+                             "self_attn.o_proj.weight", "mlp.gate_proj.weight", "mlp.up_proj.weight",
+                             "mlp.down_proj.weight"}) {
+        auto it = raw_.find(lp + nm);
+        if (it != raw_.end()) {
+          dfree(it->second.p);
+          raw_.erase(it);
+        }
+      }
+    }
+    llm_norm_ = affine("model.norm", false);
+    lm_head_ = pack_linear("lm_head.weight", "", V, H);
+    // rotary table, same fp32 op order as HF LlamaRotaryEmbedding
+    std::vector<float> tab((size_t)S * hd);
+    for (int pos = 0; pos < S; ++pos)
+      for (int d = 0; d < hd / 2; ++d) {
+        const float inv = 1.0f / powf(c.llm_rope_theta, (float)(2 * d) / (float)hd);
+        const float fr = (float)pos * inv;
+        tab[((size_t)pos * 2) * (hd / 2) + d] = cosf(fr);
+        tab[((size_t)pos * 2 + 1) * (hd / 2) + d] = sinf(fr);
+      }
+    rope_tab_ = upload_f32(tab);
+    cache_layer_stride_ = (size_t)MB * S * H;
+    kcache_ = talloc<T>(cache_layer_stride_ * c.llm_layers);
+    vcache_ = talloc<T>(cache_layer_stride_ * c.llm_layers);
+    const size_t R = (size_t)MB * S;
+    l_x_ = talloc<float>(R * H);
+    hidden_all_ = talloc<float>(R * H);
+    l_h_ = talloc<T>(R * H);
+    l_qkv_ = talloc<T>(R * 3 * H);
+    l_q_ = talloc<T>(R * H);
+    l_att_ = talloc<T>(R * H);
+    l_gu_ = talloc<T>(R * 2 * F);
+    l_act_ = talloc<T>(R * F);
+    l_logits_ = talloc<float>((size_t)MB * V);
+    l_xlast_ = talloc<float>((size_t)MB * H);
+    d_x_ = talloc<float>((size_t)MB * H);
+    d_qkv_ = talloc<float>((size_t)MB * 3 * H);
+    d_att_ = talloc<float>((size_t)MB * H);
+    d_act_ = talloc<float>((size_t)MB * F);
+    d_q_ = talloc<T>((size_t)MB * H);
+    ids_dev_ = talloc<int64_t>((size_t)MB * S);
+    next_dev_ = talloc<int64_t>(MB);
+    lens_dev_ = talloc<int>(MB);
+    slen_dev_ = talloc<int>(MB);
+    pos_dev_ = talloc<int>(MB);
+    kvlen_dev_ = talloc<int>(MB);
+    rowmap_dev_ = talloc<int>(MB);
+    idx_a_ = talloc<int>((size_t)MB * std::max(c.max_seg, 64));
+    idx_b_ = talloc<int>((size_t)MB * std::max(c.max_seg, 64));
+    HIP_TRY(hipHostMalloc((void**)&next_host_, sizeof(int64_t) * MB));
+    if (c.rephrase_weight > 0.f) ensure_q_last();
+  }
+  // ================= glue =================
+  {
+    const int H = c.llm_dim;
+    fc1_ = pack_linear_f32("model.text_hidden_fcs.0.0.weight", "model.text_hidden_fcs.0.0.bias", H, H);
+    fc2_ = pack_linear_f32("model.text_hidden_fcs.0.2.weight", "model.text_hidden_fcs.0.2.bias", c.out_dim, H);
+    has_audio_ = has_raw("model.audio_projector.weight");
+    if (has_audio_)
+      audio_proj_ = pack_linear("model.audio_projector.weight", "model.audio_projector.bias", H, c.audio_dim);
+    const size_t ns = (size_t)MB * c.max_seg;
+    seg_h_ = talloc<float>(ns * H);
+    seg_t_ = talloc<float>(ns * H);
+    pred_emb_ = talloc<float>(ns * c.out_dim);
+    attn_row_ = talloc<float>((size_t)MB * c.llm_max_seq);
+  }
+  // ================= SAM image encoder =================
+  {
+    const std::string p = std::string(SAM_P) + "image_encoder.";
+    const int D = c.sam_dim, g = c.sam_img / c.sam_patch, ws = c.sam_window, hd = D / c.sam_heads, C = c.sam_out_chans;
+    sam_g_ = g;
+    sam_nw_ = cdiv(g, ws);
+    sam_wrows_ = sam_nw_ * sam_nw_ * ws * ws;
+    sam_patch_ = pack_linear(p + "patch_embed.proj.weight", p + "patch_embed.proj.bias", D, 3 * c.sam_patch * c.sam_patch);
+    if (raw(p + "pos_embed").numel() != (int64_t)g * g * D) throw std::runtime_error("pos_embed shape mismatch");
+    sam_pos_ = own_f32(p + "pos_embed");
+    sam_blocks_.resize(c.sam_depth);
+    for (int i = 0; i < c.sam_depth; ++i) {
+      const std::string bp = p + "blocks." + std::to_string(i) + ".";
+      SamBlock& L = sam_blocks_[i];
+      for (int j = 0; j < c.sam_n_global; ++j)
+        if (c.sam_global_idx[j] == i) L.global = true;
+      L.ln1 = affine(bp + "norm1");
+      L.ln2 = affine(bp + "norm2");
+      L.qkv = pack_linear(bp + "attn.qkv.weight", bp + "attn.qkv.bias", 3 * D, D);
+      L.proj = pack_linear(bp + "attn.proj.weight", bp + "attn.proj.bias", D, D);
+      L.lin1 = pack_linear(bp + "mlp.lin1.weight", bp + "mlp.lin1.bias", c.sam_mlp_ratio * D, D);
+      L.lin2 = pack_linear(bp + "mlp.lin2.weight", bp + "mlp.lin2.bias", D, c.sam_mlp_ratio * D);
+      const int sz = L.global ? g : ws;
+      if (raw(bp + "attn.rel_pos_h").numel() != (int64_t)(2 * sz - 1) * hd)
+        throw std::runtime_error("rel_pos table of " + bp + " is not (2*size-1) x head_dim (interpolation unsupported)");
+      L.rel_h = own_f32(bp + "attn.rel_pos_h");
+      L.rel_w = own_f32(bp + "attn.rel_pos_w");
+    }
+    neck0_ = pack_linear(p + "neck.0.weight", "", C, D);
+    neck1_ = affine(p + "neck.1");
+    neck3_ = affine(p + "neck.3");
+    {  // 3x3 conv weight [O][C][3][3] -> [O][(ky*3+kx)*C + c]
+      std::vector<float> w = to_host(p + "neck.2.weight"), r((size_t)C * 9 * C);
+      if (w.size() != r.size()) throw std::runtime_error("neck.2 shape mismatch");
+      for (int o = 0; o < C; ++o)
+        for (int ci = 0; ci < C; ++ci)
+          for (int t = 0; t < 9; ++t) r[((size_t)o * 9 + t) * C + ci] = w[((size_t)o * C + ci) * 9 + t];
+      float* rf = upload_f32(r);
+      neck2_.n = C;
+      neck2_.k = 9 * C;
+      neck2_.w = talloc<T>(r.size());
+      launch_convert<T>(rf, 9 * C, neck2_.w, 9 * C, C, 9 * C, 0);
+      HIP_TRY(hipStreamSynchronize(0));
+      dfree(rf);
+    }
+    // window <-> token row maps for up to MB images
+    std::vector<int> w2t((size_t)MB * sam_wrows_), t2w((size_t)MB * g * g);
+    for (int b = 0; b < MB; ++b)
+      for (int wy = 0; wy < sam_nw_; ++wy)
+        for (int wx = 0; wx < sam_nw_; ++wx)
+          for (int ty = 0; ty < ws; ++ty)
+            for (int tx = 0; tx < ws; ++tx) {
+              const int y = wy * ws + ty, x = wx * ws + tx;
+              const int wr = b * sam_wrows_ + ((wy * sam_nw_ + wx) * ws + ty) * ws + tx;
+              if (y < g && x < g) {
+                w2t[wr] = b * g * g + y * g + x;
+                t2w[b * g * g + y * g + x] = wr;
+              } else {
+                w2t[wr] = -1;
+              }
+            }
+    win2tok_ = talloc<int>(w2t.size());
+    tok2win_ = talloc<int>(t2w.size());
+    HIP_TRY(hipMemcpy(win2tok_, w2t.data(), w2t.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(tok2win_, t2w.data(), t2w.size() * 4, hipMemcpyHostToDevice));
+    const size_t RT = (size_t)MB * g * g, RW = std::max((size_t)MB * sam_wrows_, RT);
+    s_col_ = talloc<T>(RT * sam_patch_.k);
+    s_x_ = talloc<float>(RT * D);
+    s_hwin_ = talloc<T>((size_t)MB * sam_wrows_ * D);
+    HIP_TRY(hipMemset(s_hwin_, 0, (size_t)MB * sam_wrows_ * D * sizeof(T)));  // pad rows stay zero forever
+    s_hglob_ = talloc<T>(RT * D);
+    s_qkv_ = talloc<T>(RW * 3 * D);
+    s_att_ = talloc<T>(RW * D);
+    s_mlp_ = talloc<T>(RT * c.sam_mlp_ratio * D);
+    const size_t rel_g = (size_t)MB * c.sam_heads * g * g * g;
+    const size_t rel_w = (size_t)MB * sam_nw_ * sam_nw_ * c.sam_heads * ws * ws * ws;
+    s_relh_ = talloc<float>(std::max(rel_g, rel_w));
+    s_relw_ = talloc<float>(std::max(rel_g, rel_w));
+    s_n0_ = talloc<float>(RT * C);
+    s_n1_ = talloc<T>(RT * C);
+    s_col3_ = talloc<T>(RT * 9 * C);
+    s_n2_ = talloc<float>(RT * C);
+    sam_emb_ = talloc<float>(RT * C);
+  }
+  // ================= prompt encoder + mask decoder (f32) =================
+  {
+    const std::string pp = std::string(SAM_P) + "prompt_encoder.";
+    const std::string p = std::string(SAM_P) + "mask_decoder.";
+    const int C = c.sam_out_chans, g = sam_g_, NK = g * g, nt = c.num_mask_tokens;
+    if (raw(pp + "pe_layer.positional_encoding_gaussian_matrix").numel() != C) throw std::runtime_error("gaussian matrix shape");
+    dense_pe_ = talloc<float>((size_t)NK * C);
+    launch_dense_pe(raw(pp + "pe_layer.positional_encoding_gaussian_matrix").p, g, C / 2, dense_pe_, 0);
+    no_mask_ = own_f32(pp + "no_mask_embed.weight");
+    out_tokens_ = talloc<float>((size_t)(nt + 1) * C);
+    HIP_TRY(hipMemcpy(out_tokens_, raw(p + "iou_token.weight").p, C * 4, hipMemcpyDeviceToDevice));
+    HIP_TRY(hipMemcpy(out_tokens_ + C, raw(p + "mask_tokens.weight").p, (size_t)nt * C * 4, hipMemcpyDeviceToDevice));
+    auto attn = [&](const std::string& ap, int internal) {
+      DecAttn a;
+      a.q = pack_linear_f32(ap + "q_proj.weight", ap + "q_proj.bias", internal, C);
+      a.k = pack_linear_f32(ap + "k_proj.weight", ap + "k_proj.bias", internal, C);
+      a.v = pack_linear_f32(ap + "v_proj.weight", ap + "v_proj.bias", internal, C);
+      a.o = pack_linear_f32(ap + "out_proj.weight", ap + "out_proj.bias", C, internal);
+      return a;
+    };
+    dec_layers_.resize(c.dec_depth);
+    for (int i = 0; i < c.dec_depth; ++i) {
+      const std::string lp = p + "transformer.layers." + std::to_string(i) + ".";
+      DecLayer& L = dec_layers_[i];
+      L.self = attn(lp + "self_attn.", C);
+      L.t2i = attn(lp + "cross_attn_token_to_image.", C / 2);
+      L.i2t = attn(lp + "cross_attn_image_to_token.", C / 2);
+      L.n1 = affine(lp + "norm1");
+      L.n2 = affine(lp + "norm2");
+      L.n3 = affine(lp + "norm3");
+      L.n4 = affine(lp + "norm4");
+      L.lin1 = pack_linear_f32(lp + "mlp.lin1.weight", lp + "mlp.lin1.bias", c.dec_mlp, C);
+      L.lin2 = pack_linear_f32(lp + "mlp.lin2.weight", lp + "mlp.lin2.bias", C, c.dec_mlp);
+    }
+    dec_final_ = attn(p + "transformer.final_attn_token_to_image.", C / 2);
+    dec_norm_final_ = affine(p + "transformer.norm_final_attn");
+    up_ln_ = affine(p + "output_upscaling.1");
+    auto convT = [&](const std::string& name, int cin, int cout) {  // [cin][cout][2][2] -> [(dy*2+dx)*cout+co][ci]
+      std::vector<float> w = to_host(name + ".weight"), bsrc = to_host(name + ".bias");
+      if ((int)w.size() != cin * cout * 4 || (int)bsrc.size() != cout) throw std::runtime_error("convT shape " + name);
+      std::vector<float> r((size_t)4 * cout * cin), rb((size_t)4 * cout);
+      for (int ci = 0; ci < cin; ++ci)
+        for (int co = 0; co < cout; ++co)
+          for (int t = 0; t < 4; ++t) r[((size_t)t * cout + co) * cin + ci] = w[((size_t)ci * cout + co) * 4 + t];
+      for (int t = 0; t < 4; ++t)
+        for (int co = 0; co < cout; ++co) rb[(size_t)t * cout + co] = bsrc[co];
+      LinF l;
+      l.n = 4 * cout;
+      l.k = cin;
+      l.w = upload_f32(r);
+      l.b = upload_f32(rb);
+      return l;
+    };
+    up1_ = convT(p + "output_upscaling.0", C, C / 4);
+    up2_ = convT(p + "output_upscaling.3", C / 4, C / 8);
+    // hypernetwork MLPs stacked over the mask tokens: layer j weights [nt][out][in]
+    const int dims[4] = {C, C, C, C / 8};
+    for (int j = 0; j < 3; ++j) {
+      const int in = dims[j], out = dims[j + 1];
+      hyper_[j].n = out;
+      hyper_[j].k = in;
+      hyper_[j].w = talloc<float>((size_t)nt * out * in);
+      hyper_[j].b = talloc<float>((size_t)nt * out);
+      for (int t = 0; t < nt; ++t) {
+        const std::string hp = p + "output_hypernetworks_mlps." + std::to_string(t) + ".layers." + std::to_string(j);
+        if (raw(hp + ".weight").numel() != (int64_t)out * in) throw std::runtime_error("hyper mlp shape " + hp);
+        HIP_TRY(hipMemcpy(hyper_[j].w + (size_t)t * out * in, raw(hp + ".weight").p, (size_t)out * in * 4,
+                          hipMemcpyDeviceToDevice));
+        HIP_TRY(hipMemcpy(hyper_[j].b + (size_t)t * out, raw(hp + ".bias").p, (size_t)out * 4, hipMemcpyDeviceToDevice));
+      }
+    }
+    const int idims[4] = {C, C, C, nt};
+    for (int j = 0; j < 3; ++j) {
+      const std::string ip = p + "iou_prediction_head.layers." + std::to_string(j);
+      if (idims[j + 1] % 1) {}
+      iou_head_[j] = pack_linear_f32(ip + ".weight", ip + ".bias", idims[j + 1], idims[j]);
+    }
+    const int n = c.max_seg, NQ = nt + 2;
+    m_tokens_ = talloc<float>((size_t)n * NQ * C);
+    m_q_ = talloc<float>((size_t)n * NQ * C);
+    m_qp_ = talloc<float>((size_t)n * NQ * C);
+    m_qh_ = talloc<float>((size_t)n * NQ * C);
+    m_kh_ = talloc<float>((size_t)n * NQ * C);
+    m_vh_ = talloc<float>((size_t)n * NQ * C);
+    m_att_ = talloc<float>((size_t)n * NQ * C);
+    m_tmp_ = talloc<float>((size_t)n * NQ * C);
+    m_mlp_ = talloc<float>((size_t)n * NQ * c.dec_mlp);
+    m_src_ = talloc<float>((size_t)NK * C);
+    m_keys_ = talloc<float>((size_t)n * NK * C);
+    m_kp_ = talloc<float>((size_t)n * NK * C);
+    m_bigq_ = talloc<float>((size_t)n * NK * C / 2);
+    m_bigk_ = talloc<float>((size_t)n * NK * C / 2);
+    m_bigv_ = talloc<float>((size_t)n * NK * C / 2);
+    m_bigatt_ = talloc<float>((size_t)n * NK * C / 2);
+    m_up0_ = talloc<float>((size_t)n * NK * C);              // ConvT1 GEMM out [n*NK, 4*C/4]
+    m_up1_ = talloc<float>((size_t)n * 4 * NK * (C / 4));    // [n*(2g)^2, C/4]
+    m_up2_ = talloc<float>((size_t)n * 4 * NK * (C / 2));    // ConvT2 GEMM out [n*4NK, 4*C/8]
+    m_hy0_ = talloc<float>((size_t)nt * n * C);
+    m_hy1_ = talloc<float>((size_t)nt * n * C);
+    m_hyper_ = talloc<float>((size_t)n * nt * (C / 8));
+    m_masks_ = talloc<float>((size_t)n * nt * 16 * NK);
+    m_iou_ = talloc<float>((size_t)n * nt);
+  }
+  HIP_TRY(hipDeviceSynchronize());
+  drop_raw();
+  finalized_ = true;
+}
+
+template <typename T>
+void Model<T>::ensure_q_last() {
+  if (!q_last_) q_last_ = talloc<T>((size_t)cfg.max_batch * cfg.llm_max_seq * cfg.llm_dim);
+}
+
+// ---------------------------------------------------------------------------------------------
+// CLIP tower + projector
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+void Model<T>::clip_tower(hipStream_t s, const float* images, int B) {
+  const anyref_config& c = cfg;
+  const int Dc = c.clip_dim, n = clip_n_, S = n + 1, R = B * S, hd = Dc / c.clip_heads;
+  launch_im2col_patch<T>(images, B, c.clip_image, c.clip_patch, c_col_, clip_kp_, s);
+  gemm(s, c_col_, clip_kp_, clip_patch_, c_patch_, Dc, B * n, ACT_NONE, true);
+  launch_clip_assemble(c_patch_, clip_cls_, clip_pos_, c_x_, B, n, Dc, s);
+  norm(s, c_x_, Dc, clip_pre_, c_x_, Dc, R, Dc, c.clip_eps, true);
+  for (auto& L : clip_layers_) {
+    norm(s, c_x_, Dc, L.ln1, c_h_, Dc, R, Dc, c.clip_eps, false);
+    gemm(s, c_h_, Dc, L.qkv, c_qkv_, 3 * Dc, R, ACT_NONE, false);
+    AttnArgs a;
+    a.Q = c_qkv_; a.K = c_qkv_ + Dc; a.V = c_qkv_ + 2 * Dc; a.O = c_att_;
+    a.q_bs = a.k_bs = a.v_bs = (int64_t)S * 3 * Dc;
+    a.q_rs = a.k_rs = a.v_rs = 3 * Dc;
+    a.q_hs = a.k_hs = a.v_hs = hd;
+    a.o_bs = (int64_t)S * Dc; a.o_rs = Dc; a.o_hs = hd;
+    a.B = B; a.H = c.clip_heads; a.Sq = S; a.Sk = S; a.hd = hd;
+    a.scale = 1.f / sqrtf((float)hd);
+    launch_attention<T>(a, s);
+    gemm(s, c_att_, Dc, L.out, c_x_, Dc, R, ACT_NONE, true, c_x_, Dc);
+    norm(s, c_x_, Dc, L.ln2, c_h_, Dc, R, Dc, c.clip_eps, false);
+    gemm(s, c_h_, Dc, L.fc1, c_mlp_, c.clip_mlp, R, ACT_QUICK_GELU, false);
+    gemm(s, c_mlp_, c.clip_mlp, L.fc2, c_x_, Dc, R, ACT_NONE, true, c_x_, Dc);
+  }
+  for (int b = 0; b < B; ++b)  // drop CLS ("patch" feature select)
+    launch_convert<T>(c_x_ + ((size_t)b * S + 1) * Dc, Dc, c_feat_ + (size_t)b * n * Dc, Dc, n, Dc, s);
+  gemm(s, c_feat_, Dc, mm_proj_, img_feat_, c.llm_dim, B * n, ACT_NONE, true);
+}
+
+template <typename T>
+void Model<T>::encode_images(hipStream_t s, const float* clip_images, int B, float* out, float* clip_feat) {
+  HIP_TRY(hipSetDevice(device_));
+  if (B > cfg.max_batch) throw std::runtime_error("batch exceeds max_batch");
+  clip_tower(s, clip_images, B);
+  HIP_TRY(hipMemcpyAsync(out, img_feat_, (size_t)B * clip_n_ * cfg.llm_dim * 4, hipMemcpyDeviceToDevice, s));
+  if (clip_feat)
+    for (int b = 0; b < B; ++b)
+      HIP_TRY(hipMemcpyAsync(clip_feat + (size_t)b * clip_n_ * cfg.clip_dim,
+                             c_x_ + ((size_t)b * (clip_n_ + 1) + 1) * cfg.clip_dim,
+                             (size_t)clip_n_ * cfg.clip_dim * 4, hipMemcpyDeviceToDevice, s));
+}
+
+template <typename T>
+void Model<T>::project_audio(hipStream_t s, const float* audio_emb, int n, float* out) {
+  HIP_TRY(hipSetDevice(device_));
+  if (!has_audio_) throw std::runtime_error("model.audio_projector.* was not provided");
+  if (n > cfg.max_batch * 64) throw std::runtime_error("too many audio rows");
+  // stage through the LLM scratch (idle at this point)
+  launch_convert<T>(audio_emb, cfg.audio_dim, l_h_, cfg.audio_dim, n, cfg.audio_dim, s);
+  gemm(s, l_h_, cfg.audio_dim, audio_proj_, out, cfg.llm_dim, n, ACT_NONE, true);
+}
+
+// ---------------------------------------------------------------------------------------------
+// LLaMA
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+void Model<T>::llm_prefill(hipStream_t s, int B, int Sp, const int* lens_dev, bool keep_q) {
+  // l_x_ holds the spliced embeddings [B,Sp,H] (compact).  Fills the KV cache, hidden_all_[b, 0:Sp]
+  // (post final norm) and next_dev_ (greedy token after each prompt).
+  const anyref_config& c = cfg;
+  const int H = c.llm_dim, F = c.llm_mlp, nh = c.llm_heads, hd = H / nh, S = c.llm_max_seq, R = B * Sp;
+  const int nl = c.llm_layers;
+  for (int i = 0; i < nl; ++i) {
+    LlmLayer& L = llm_layers_[i];
+    T* kc = kcache_ + cache_layer_stride_ * i;
+    T* vc = vcache_ + cache_layer_stride_ * i;
+    norm(s, l_x_, H, L.in_norm, l_h_, H, R, H, c.llm_rms_eps, false, true);
+    gemm(s, l_h_, H, L.qkv, l_qkv_, 3 * H, R, ACT_NONE, false);
+    launch_rope_cache<T>(l_qkv_, B, Sp, nh, hd, nullptr, lens_dev, rope_tab_, l_q_, kc, vc, S,
+                         (keep_q && i == nl - 1) ? q_last_ : nullptr, s);
+    AttnArgs a;
+    a.Q = l_q_; a.K = kc; a.V = vc; a.O = l_att_;
+    a.q_bs = (int64_t)Sp * H; a.q_rs = H; a.q_hs = hd;
+    a.k_bs = a.v_bs = (int64_t)S * H; a.k_rs = a.v_rs = H; a.k_hs = a.v_hs = hd;
+    a.o_bs = (int64_t)Sp * H; a.o_rs = H; a.o_hs = hd;
+    a.B = B; a.H = nh; a.Sq = Sp; a.Sk = Sp; a.hd = hd;
+    a.scale = 1.f / sqrtf((float)hd);
+    a.causal = 1; a.kv_len = lens_dev; a.q_len = lens_dev;
+    launch_attention<T>(a, s);
+    gemm(s, l_att_, H, L.o, l_x_, H, R, ACT_NONE, true, l_x_, H);
+    norm(s, l_x_, H, L.post_norm, l_h_, H, R, H, c.llm_rms_eps, false, true);
+    gemm(s, l_h_, H, L.gu, l_gu_, 2 * F, R, ACT_NONE, false);
+    launch_swiglu<T>(l_gu_, R, F, l_act_, s);
+    gemm(s, l_act_, F, L.down, l_x_, H, R, ACT_NONE, true, l_x_, H);
+  }
+  for (int b = 0; b < B; ++b)
+    norm(s, l_x_ + (size_t)b * Sp * H, H, llm_norm_, hidden_all_ + (size_t)b * S * H, H, Sp, H, c.llm_rms_eps, true,
+         true);
+}
+
+template <typename T>
+void Model<T>::llm_decode_step(hipStream_t s, int B, bool keep_q) {
+  // next_dev_ -> embed -> all layers at pos_dev_ -> hidden_all_[b,pos] -> logits -> next_dev_; pos += 1
+  const anyref_config& c = cfg;
+  const int H = c.llm_dim, F = c.llm_mlp, nh = c.llm_heads, hd = H / nh, S = c.llm_max_seq, nl = c.llm_layers;
+  launch_embed_rows(next_dev_, B, emb_table_, sizeof(T) == 2, H, d_x_, s);
+  launch_decode_index(pos_dev_, B, S, rowmap_dev_, kvlen_dev_, s);
+  for (int i = 0; i < nl; ++i) {
+    LlmLayer& L = llm_layers_[i];
+    T* kc = kcache_ + cache_layer_stride_ * i;
+    T* vc = vcache_ + cache_layer_stride_ * i;
+    GemvArgs g;
+    g.x = d_x_; g.ldx = H; g.gain = L.in_norm.g; g.eps = c.llm_rms_eps; g.W = L.qkv.w; g.y = d_qkv_;
+    g.ldy = 3 * H; g.B = B; g.N = 3 * H; g.K = H;
+    launch_gemv<T>(g, s);
+    launch_rope_cache_f32<T>(d_qkv_, B, nh, hd, pos_dev_, rope_tab_, d_q_, kc, vc, S,
+                             (keep_q && i == nl - 1) ? q_last_ : nullptr, s);
+    AttnArgs a;
+    a.Q = d_q_; a.K = kc; a.V = vc; a.O = d_att_; a.o_f32 = 1;
+    a.q_bs = H; a.q_rs = H; a.q_hs = hd;
+    a.k_bs = a.v_bs = (int64_t)S * H; a.k_rs = a.v_rs = H; a.k_hs = a.v_hs = hd;
+    a.o_bs = H; a.o_rs = H; a.o_hs = hd;
+    a.B = B; a.H = nh; a.Sq = 1; a.Sk = S; a.hd = hd;
+    a.scale = 1.f / sqrtf((float)hd);
+    a.kv_len = kvlen_dev_;
+    launch_attention<T>(a, s);
+    GemvArgs o;
+    o.x = d_att_; o.ldx = H; o.W = L.o.w; o.y = d_x_; o.resid = d_x_; o.ldy = H; o.B = B; o.N = H; o.K = H;
+    launch_gemv<T>(o, s);
+    GemvArgs m;
+    m.x = d_x_; m.ldx = H; m.gain = L.post_norm.g; m.eps = c.llm_rms_eps; m.W = L.gate_w; m.W2 = L.up_w;
+    m.y = d_act_; m.ldy = F; m.B = B; m.N = F; m.K = H;
+    launch_gemv<T>(m, s);
+    GemvArgs d;
+    d.x = d_act_; d.ldx = F; d.W = L.down.w; d.y = d_x_; d.resid = d_x_; d.ldy = H; d.B = B; d.N = H; d.K = F;
+    launch_gemv<T>(d, s);
+  }
+  NormArgs n;
+  n.x = d_x_; n.ldx = H; n.gain = llm_norm_.g; n.y = hidden_all_; n.ldy = H; n.M = B; n.D = H;
+  n.eps = c.llm_rms_eps; n.rms = 1; n.y_f32 = 1; n.row_map = rowmap_dev_;
+  launch_norm<T>(n, s);
+  GemvArgs h;
+  h.x = d_x_; h.ldx = H; h.gain = llm_norm_.g; h.eps = c.llm_rms_eps; h.W = lm_head_.w; h.y = l_logits_;
+  h.ldy = c.llm_vocab; h.B = B; h.N = c.llm_vocab; h.K = H;
+  launch_gemv<T>(h, s);
+  launch_argmax(l_logits_, B, c.llm_vocab, c.llm_vocab, next_dev_, s);
+  launch_add_i32(pos_dev_, 1, B, s);
+}
+
+template <typename T>
+void Model<T>::llm_forward(hipStream_t s, const float* embeds, const int32_t* lens, int B, int Sn, float* hidden,
+                           float* logits, const int32_t* attn_q, float* attn_row) {
+  HIP_TRY(hipSetDevice(device_));
+  const anyref_config& c = cfg;
+  if (B > c.max_batch || Sn > c.llm_max_seq) throw std::runtime_error("llm_forward: batch/seq exceed the model's limits");
+  const int H = c.llm_dim;
+  HIP_TRY(hipMemcpyAsync(l_x_, embeds, (size_t)B * Sn * H * 4, hipMemcpyDeviceToDevice, s));
+  HIP_TRY(hipMemcpyAsync(lens_dev_, lens, B * 4, hipMemcpyHostToDevice, s));
+  const bool keep_q = attn_q != nullptr;
+  if (keep_q) ensure_q_last();
+  llm_prefill(s, B, Sn, lens_dev_, keep_q);
+  for (int b = 0; b < B; ++b)
+    HIP_TRY(hipMemcpyAsync(hidden + (size_t)b * Sn * H, hidden_all_ + (size_t)b * c.llm_max_seq * H,
+                           (size_t)Sn * H * 4, hipMemcpyDeviceToDevice, s));
+  if (logits) {
+    launch_convert<T>(hidden, H, l_h_, H, B * Sn, H, s);
+    gemm(s, l_h_, H, lm_head_, logits, c.llm_vocab, B * Sn, ACT_NONE, true);
+  }
+  if (attn_q) {
+    const int nh = c.llm_heads, hd = H / nh, S = c.llm_max_seq;
+    std::vector<int> kl(B);
+    for (int b = 0; b < B; ++b) kl[b] = attn_q[b] + 1;
+    HIP_TRY(hipMemcpyAsync(kvlen_dev_, kl.data(), B * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    T* kc = kcache_ + cache_layer_stride_ * (c.llm_layers - 1);
+    for (int b = 0; b < B; ++b)
+      launch_attn_row_mean<T>(q_last_ + ((size_t)b * S + attn_q[b]) * H, 0, hd, kc + (size_t)b * S * H, 0, H, hd,
+                              kvlen_dev_ + b, 1, nh, hd, 1.f / sqrtf((float)hd), attn_row + (size_t)b * Sn, Sn, s);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// SAM image encoder
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+void Model<T>::sam_encoder(hipStream_t s, const float* images, int B, float* out) {
+  const anyref_config& c = cfg;
+  const int D = c.sam_dim, g = sam_g_, NT = g * g, RT = B * NT, ws = c.sam_window, nh = c.sam_heads, hd = D / nh;
+  const int C = c.sam_out_chans, WR = sam_wrows_, nW = sam_nw_ * sam_nw_;
+  launch_im2col_patch<T>(images, B, c.sam_img, c.sam_patch, s_col_, sam_patch_.k, s);
+  {
+    GemmArgs a;
+    a.A = s_col_; a.lda = sam_patch_.k; a.W = sam_patch_.w; a.ldw = sam_patch_.k; a.bias = sam_patch_.b;
+    a.C = s_x_; a.ldc = D; a.M = NT; a.N = D; a.K = sam_patch_.k; a.c_f32 = 1;
+    a.resid = sam_pos_; a.ldr = D;  // + absolute position embedding, shared by every image
+    a.batch = B; a.sA = (int64_t)NT * sam_patch_.k; a.sC = (int64_t)NT * D; a.sR = 0;
+    launch_gemm<T>(a, s);
+  }
+  for (auto& L : sam_blocks_) {
+    AttnArgs a;
+    a.q_hs = a.k_hs = a.v_hs = hd; a.o_hs = hd;
+    a.q_rs = a.k_rs = a.v_rs = 3 * D; a.o_rs = D;
+    a.H = nh; a.hd = hd; a.scale = 1.f / sqrtf((float)hd);
+    a.Q = s_qkv_; a.K = s_qkv_ + D; a.V = s_qkv_ + 2 * D; a.O = s_att_;
+    a.rel_h = s_relh_; a.rel_w = s_relw_;
+    if (L.global) {
+      norm(s, s_x_, D, L.ln1, s_hglob_, D, RT, D, 1e-6f, false);
+      gemm(s, s_hglob_, D, L.qkv, s_qkv_, 3 * D, RT, ACT_NONE, false);
+      launch_rel_pos<T>(s_qkv_, (int64_t)NT * 3 * D, 3 * D, hd, L.rel_h, L.rel_w, B, nh, g, hd, s_relh_, s_relw_, s);
+      a.q_bs = a.k_bs = a.v_bs = (int64_t)NT * 3 * D; a.o_bs = (int64_t)NT * D;
+      a.B = B; a.Sq = NT; a.Sk = NT; a.kh = g; a.kw = g;
+      launch_attention<T>(a, s);
+      gemm(s, s_att_, D, L.proj, s_x_, D, RT, ACT_NONE, true, s_x_, D);
+    } else {
+      const int RW = B * WR, S2 = ws * ws;
+      norm(s, s_x_, D, L.ln1, s_hwin_, D, RT, D, 1e-6f, false, false, tok2win_);
+      gemm(s, s_hwin_, D, L.qkv, s_qkv_, 3 * D, RW, ACT_NONE, false);
+      launch_rel_pos<T>(s_qkv_, (int64_t)S2 * 3 * D, 3 * D, hd, L.rel_h, L.rel_w, B * nW, nh, ws, hd, s_relh_, s_relw_, s);
+      a.q_bs = a.k_bs = a.v_bs = (int64_t)S2 * 3 * D; a.o_bs = (int64_t)S2 * D;
+      a.B = B * nW; a.Sq = S2; a.Sk = S2; a.kh = ws; a.kw = ws;
+      launch_attention<T>(a, s);
+      gemm(s, s_att_, D, L.proj, s_x_, D, RW, ACT_NONE, true, s_x_, D, win2tok_);
+    }
+    norm(s, s_x_, D, L.ln2, s_hglob_, D, RT, D, 1e-6f, false);
+    gemm(s, s_hglob_, D, L.lin1, s_mlp_, c.sam_mlp_ratio * D, RT, ACT_GELU, false);
+    gemm(s, s_mlp_, c.sam_mlp_ratio * D, L.lin2, s_x_, D, RT, ACT_NONE, true, s_x_, D);
+  }
+  // neck: 1x1 conv -> LN2d -> 3x3 conv -> LN2d (channels-last tokens; fp32 LayerNorm as the
+  // reference forces under fp16, image_encoder.py:119-122)
+  launch_convert<T>(s_x_, D, s_hglob_, D, RT, D, s);
+  gemm(s, s_hglob_, D, neck0_, s_n0_, C, RT, ACT_NONE, true);
+  norm(s, s_n0_, C, neck1_, s_n1_, C, RT, C, 1e-6f, false);
+  launch_im2col_3x3<T>(s_n1_, B, g, C, s_col3_, s);
+  gemm(s, s_col3_, 9 * C, neck2_, s_n2_, C, RT, ACT_NONE, true);
+  norm(s, s_n2_, C, neck3_, out, C, RT, C, 1e-6f, true);
+}
+
+template <typename T>
+void Model<T>::sam_encode(hipStream_t s, const float* sam_images, int B, float* out) {
+  HIP_TRY(hipSetDevice(device_));
+  if (B > cfg.max_batch) throw std::runtime_error("batch exceeds max_batch");
+  sam_encoder(s, sam_images, B, out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// prompt encoder (text) + mask decoder, all f32
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+void Model<T>::mask_decoder(hipStream_t s, const float* image_emb, const float* pred_emb, int n, float* masks4,
+                            float* iou) {
+  const anyref_config& c = cfg;
+  const int C = c.sam_out_chans, g = sam_g_, NK = g * g, nt = c.num_mask_tokens, NQ = nt + 2, Ci = C / 2;
+  const int nh = c.dec_heads;
+  // tokens = [iou, mask x nt, text prompt]; src = image embedding + no_mask dense embedding
+  launch_build_tokens(out_tokens_, nt + 1, pred_emb, n, C, m_tokens_, s);
+  launch_add_vec(image_emb, no_mask_, m_src_, NK, C, s);
+  for (int i = 0; i < n; ++i)
+    HIP_TRY(hipMemcpyAsync(m_keys_ + (size_t)i * NK * C, m_src_, (size_t)NK * C * 4, hipMemcpyDeviceToDevice, s));
+  HIP_TRY(hipMemcpyAsync(m_q_, m_tokens_, (size_t)n * NQ * C * 4, hipMemcpyDeviceToDevice, s));
+
+  auto attn = [&](const float* Q, const float* K, const float* V, float* O, int Sq, int Sk, int internal) {
+    AttnArgs a;
+    const int hd = internal / nh;
+    a.Q = Q; a.K = K; a.V = V; a.O = O;
+    a.q_bs = (int64_t)Sq * internal; a.q_rs = internal; a.q_hs = hd;
+    a.k_bs = a.v_bs = (int64_t)Sk * internal; a.k_rs = a.v_rs = internal; a.k_hs = a.v_hs = hd;
+    a.o_bs = (int64_t)Sq * internal; a.o_rs = internal; a.o_hs = hd;
+    a.B = n; a.H = nh; a.Sq = Sq; a.Sk = Sk; a.hd = hd; a.scale = 1.f / sqrtf((float)hd);
+    launch_attention<float>(a, s);
+  };
+  auto lnf = [&](float* x, const Affine& af, int M) {
+    NormArgs a;
+    a.x = x; a.ldx = C; a.gain = af.g; a.bias = af.b; a.y = x; a.ldy = C; a.M = M; a.D = C; a.eps = 1e-5f; a.y_f32 = 1;
+    launch_norm<float>(a, s);
+  };
+  // token -> image attention with weights `A`; queries += out
+  auto token_to_image = [&](const DecAttn& A) {
+    launch_add_rows(m_q_, m_tokens_, n * NQ, m_qp_, n * NQ, C, s);   // q = queries + query_pe
+    launch_add_rows(m_keys_, dense_pe_, NK, m_kp_, n * NK, C, s);    // k = keys + key_pe
+    gemmf(s, m_qp_, C, A.q, m_qh_, Ci, n * NQ, ACT_NONE);
+    gemmf(s, m_kp_, C, A.k, m_bigk_, Ci, n * NK, ACT_NONE);
+    gemmf(s, m_keys_, C, A.v, m_bigv_, Ci, n * NK, ACT_NONE);
+    attn(m_qh_, m_bigk_, m_bigv_, m_att_, NQ, NK, Ci);
+    gemmf(s, m_att_, Ci, A.o, m_q_, C, n * NQ, ACT_NONE, m_q_, C);
+  };
+
+  for (int i = 0; i < c.dec_depth; ++i) {
+    DecLayer& L = dec_layers_[i];
+    // (1) self attention of the tokens (layer 0: no PE, output replaces the queries; transformer.py:153-160)
+    const float* qin = m_q_;
+    if (i > 0) {
+      launch_add_rows(m_q_, m_tokens_, n * NQ, m_qp_, n * NQ, C, s);
+      qin = m_qp_;
+    }
+    gemmf(s, qin, C, L.self.q, m_qh_, C, n * NQ, ACT_NONE);
+    gemmf(s, qin, C, L.self.k, m_kh_, C, n * NQ, ACT_NONE);
+    gemmf(s, m_q_, C, L.self.v, m_vh_, C, n * NQ, ACT_NONE);
+    attn(m_qh_, m_kh_, m_vh_, m_att_, NQ, NQ, C);
+    if (i == 0)
+      gemmf(s, m_att_, C, L.self.o, m_q_, C, n * NQ, ACT_NONE);
+    else
+      gemmf(s, m_att_, C, L.self.o, m_q_, C, n * NQ, ACT_NONE, m_q_, C);
+    lnf(m_q_, L.n1, n * NQ);
+    // (2) tokens attend to the image
+    token_to_image(L.t2i);
+    lnf(m_q_, L.n2, n * NQ);
+    // (3) MLP on the tokens
+    gemmf(s, m_q_, C, L.lin1, m_mlp_, c.dec_mlp, n * NQ, ACT_RELU);
+    gemmf(s, m_mlp_, c.dec_mlp, L.lin2, m_q_, C, n * NQ, ACT_NONE, m_q_, C);
+    lnf(m_q_, L.n3, n * NQ);
+    // (4) image attends to the tokens: q = keys + key_pe, k = queries + query_pe, v = queries
+    launch_add_rows(m_q_, m_tokens_, n * NQ, m_qp_, n * NQ, C, s);
+    launch_add_rows(m_keys_, dense_pe_, NK, m_kp_, n * NK, C, s);
+    gemmf(s, m_kp_, C, L.i2t.q, m_bigq_, Ci, n * NK, ACT_NONE);
+    gemmf(s, m_qp_, C, L.i2t.k, m_kh_, Ci, n * NQ, ACT_NONE);
+    gemmf(s, m_q_, C, L.i2t.v, m_vh_, Ci, n * NQ, ACT_NONE);
+    attn(m_bigq_, m_kh_, m_vh_, m_bigatt_, NK, NQ, Ci);
+    gemmf(s, m_bigatt_, Ci, L.i2t.o, m_keys_, C, n * NK, ACT_NONE, m_keys_, C);
+    lnf(m_keys_, L.n4, n * NK);
+  }
+  token_to_image(dec_final_);
+  lnf(m_q_, dec_norm_final_, n * NQ);
+
+  // ---- upscaler: ConvT(k2s2) = GEMM + un-shuffle, LayerNorm2d + GELU, ConvT, GELU, hyper product ----
+  gemmf(s, m_keys_, C, up1_, m_up0_, C, n * NK, ACT_NONE);
+  launch_upscale1<float>(m_up0_, n, g, C / 4, up_ln_.g, up_ln_.b, 1e-6f, m_up1_, s);
+  gemmf(s, m_up1_, C / 4, up2_, m_up2_, C / 2, n * 4 * NK, ACT_NONE);
+  // hypernetwork MLPs, batched over the mask tokens (A = hs[:, 1+t, :])
+  for (int j = 0; j < 3; ++j) {
+    GemmArgs a;
+    const int in = hyper_[j].k, outn = hyper_[j].n;
+    if (j == 0) {
+      a.A = m_q_ + C; a.lda = NQ * C; a.sA = C;
+    } else {
+      a.A = j == 1 ? m_hy0_ : m_hy1_; a.lda = in; a.sA = (int64_t)n * in;
+    }
+    a.W = hyper_[j].w; a.ldw = in; a.sW = (int64_t)outn * in;
+    a.bias = hyper_[j].b; a.sBias = outn;
+    if (j < 2) {
+      a.C = j == 0 ? m_hy0_ : m_hy1_; a.ldc = outn; a.sC = (int64_t)n * outn; a.act = ACT_RELU;
+    } else {
+      a.C = m_hyper_; a.ldc = nt * outn; a.sC = outn;  // -> [n][nt][C/8]
+    }
+    a.M = n; a.N = outn; a.K = in; a.c_f32 = 1; a.batch = nt;
+    launch_gemm<float>(a, s);
+  }
+  launch_upscale2_masks(m_up2_, m_hyper_, n, nt, 2 * g, C / 8, masks4 ? masks4 : m_masks_, s);
+  if (iou) {
+    gemmf(s, m_q_, NQ * C, iou_head_[0], m_hy0_, C, n, ACT_RELU);
+    gemmf(s, m_hy0_, C, iou_head_[1], m_hy1_, C, n, ACT_RELU);
+    // last layer has N = nt (not a multiple of 4 in K? K = C, fine)
+    gemmf(s, m_hy1_, C, iou_head_[2], iou, nt, n, ACT_NONE);
+  }
+}
+
+template <typename T>
+void Model<T>::mask_decode(hipStream_t s, const float* image_emb, const float* pred_emb, int n, float* masks4,
+                           float* iou, const int32_t* resized_hw, const int32_t* orig_hw, float* out_masks) {
+  HIP_TRY(hipSetDevice(device_));
+  if (n > cfg.max_seg) throw std::runtime_error("more prompts than max_seg");
+  if (n <= 0) return;
+  mask_decoder(s, image_emb, pred_emb, n, masks4, iou);
+  if (out_masks) {
+    const int L = 4 * sam_g_;
+    const float* m = masks4 ? masks4 : m_masks_;
+    launch_postprocess(m, (int64_t)cfg.num_mask_tokens * L * L, n, L, L, cfg.sam_img, resized_hw[0], resized_hw[1],
+                       orig_hw[0], orig_hw[1], out_masks, s);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// generate / forward
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+int Model<T>::splice_inputs(hipStream_t s, const int64_t* input_ids, const int32_t* lens, int B, int Lmax,
+                            const float* extra_embeds, const int32_t* extra_slots, int n_extra,
+                            std::vector<int>& slen, std::vector<int>& img_pos) {
+  const anyref_config& c = cfg;
+  const int n_img = clip_n_, H = c.llm_dim;
+  slen.assign(B, 0);
+  img_pos.assign(B, -1);
+  int Sp = 0;
+  for (int b = 0; b < B; ++b) {
+    if (lens[b] <= 0 || lens[b] > Lmax) throw std::runtime_error("bad prompt length");
+    for (int i = 0; i < lens[b]; ++i)
+      if (input_ids[(size_t)b * Lmax + i] == -200) {
+        if (img_pos[b] >= 0) throw std::runtime_error("more than one image placeholder in a prompt");
+        img_pos[b] = i;
+      }
+    slen[b] = lens[b] + (img_pos[b] >= 0 ? n_img - 1 : 0);
+    Sp = std::max(Sp, slen[b]);
+  }
+  if (Sp > c.llm_max_seq) throw std::runtime_error("prompt longer than llm_max_seq");
+  HIP_TRY(hipMemcpyAsync(ids_dev_, input_ids, (size_t)B * Lmax * 8, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(lens_dev_, lens, B * 4, hipMemcpyHostToDevice, s));
+  launch_embed_splice(ids_dev_, lens_dev_, B, Lmax, emb_table_, sizeof(T) == 2, c.llm_vocab, img_feat_, n_img, l_x_, Sp,
+                      H, slen_dev_, s);
+  if (n_extra > 0) {
+    std::vector<int> eb(n_extra), ep(n_extra);
+    for (int i = 0; i < n_extra; ++i) {
+      const int b = extra_slots[2 * i], p = extra_slots[2 * i + 1];
+      if (b < 0 || b >= B || p < 0 || p >= lens[b]) throw std::runtime_error("extra slot out of range");
+      eb[i] = b;
+      ep[i] = (img_pos[b] >= 0 && p > img_pos[b]) ? p + n_img - 1 : p;
+    }
+    if (n_extra > (int)cfg.max_batch * std::max(cfg.max_seg, 64)) throw std::runtime_error("too many extra slots");
+    HIP_TRY(hipMemcpyAsync(idx_a_, eb.data(), n_extra * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(idx_b_, ep.data(), n_extra * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));  // eb/ep are stack-backed
+    launch_scatter_rows(extra_embeds, idx_a_, idx_b_, n_extra, l_x_, Sp, H, s);
+  }
+  return Sp;
+}
+
+template <typename T>
+void Model<T>::run_tail(hipStream_t s, const float* sam_images, int B, const std::vector<int>& seg_b,
+                        const std::vector<int>& seg_pos, const std::vector<int>& reph_s, const int32_t* resized_hw,
+                        const int32_t* orig_hw, int32_t* out_nseg, float* out_masks, int64_t out_masks_cap,
+                        int64_t* mask_offsets, float* out_low) {
+  // seg_b/seg_pos: (image, row of hidden_all_) of every [SEG]; reph_s: rephrase start row per image
+  const anyref_config& c = cfg;
+  const int H = c.llm_dim, S = c.llm_max_seq, nseg = (int)seg_b.size();
+  for (int b = 0; b < B; ++b) out_nseg[b] = 0;
+  for (int i = 0; i < nseg; ++i) out_nseg[seg_b[i]]++;
+  for (int b = 0; b < B; ++b)
+    if (out_nseg[b] > c.max_seg) throw std::runtime_error("more [SEG] tokens in one image than max_seg");
+  int64_t off = 0;
+  for (int b = 0; b < B; ++b) {
+    mask_offsets[b] = off;
+    off += (int64_t)out_nseg[b] * orig_hw[2 * b] * orig_hw[2 * b + 1];
+  }
+  if (off > out_masks_cap) throw std::runtime_error("out_masks capacity too small");
+  if (nseg == 0) return;
+  HIP_TRY(hipMemcpyAsync(idx_a_, seg_b.data(), nseg * 4, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(idx_b_, seg_pos.data(), nseg * 4, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  launch_gather_rows(hidden_all_, S, H, idx_a_, idx_b_, nseg, seg_h_, s);
+  if (c.rephrase_weight > 0.f) {
+    // anyref.py:735-755,767-769: the first [SEG] of image i gets + w * sum_j attn_j * hidden_j
+    const int nh = c.llm_heads, hd = H / nh;
+    T* kc = kcache_ + cache_layer_stride_ * (c.llm_layers - 1);
+    std::vector<char> done(B, 0);
+    for (int i = 0; i < nseg; ++i) {
+      const int b = seg_b[i];
+      if (done[b]) continue;
+      done[b] = 1;
+      const int e0 = seg_pos[i], s0 = reph_s[b];
+      if (e0 <= s0) continue;
+      const int kl = e0 + 1;
+      HIP_TRY(hipMemcpyAsync(kvlen_dev_ + b, &kl, 4, hipMemcpyHostToDevice, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      launch_attn_row_mean<T>(q_last_ + ((size_t)b * S + e0) * H, 0, hd, kc + (size_t)b * S * H, 0, H, hd,
+                              kvlen_dev_ + b, 1, nh, hd, 1.f / sqrtf((float)hd), attn_row_ + (size_t)b * S, S, s);
+      launch_rephrase(hidden_all_ + (size_t)b * S * H, H, attn_row_ + (size_t)b * S, s0, e0, c.rephrase_weight,
+                      seg_h_ + (size_t)i * H, s);
+    }
+  }
+  gemmf(s, seg_h_, H, fc1_, seg_t_, H, nseg, ACT_RELU);
+  gemmf(s, seg_t_, H, fc2_, pred_emb_, c.out_dim, nseg, ACT_NONE);
+  sam_encoder(s, sam_images, B, sam_emb_);
+  const int NK = sam_g_ * sam_g_, C = c.sam_out_chans, L = 4 * sam_g_;
+  int row = 0;
+  for (int b = 0; b < B; ++b) {
+    const int n = out_nseg[b];
+    if (n == 0) continue;
+    // seg rows of image b are contiguous because the host emits them image by image
+    mask_decoder(s, sam_emb_ + (size_t)b * NK * C, pred_emb_ + (size_t)row * c.out_dim, n, nullptr, nullptr);
+    launch_postprocess(m_masks_, (int64_t)c.num_mask_tokens * L * L, n, L, L, c.sam_img, resized_hw[2 * b],
+                       resized_hw[2 * b + 1], orig_hw[2 * b], orig_hw[2 * b + 1], out_masks + mask_offsets[b], s);
+    if (out_low)
+      for (int j = 0; j < n; ++j)
+        HIP_TRY(hipMemcpyAsync(out_low + ((size_t)b * c.max_seg + j) * L * L,
+                               m_masks_ + (size_t)j * c.num_mask_tokens * L * L, (size_t)L * L * 4,
+                               hipMemcpyDeviceToDevice, s));
+    row += n;
+  }
+}
+
+template <typename T>
+void Model<T>::generate(hipStream_t s, const float* clip_images, const float* sam_images, const int64_t* input_ids,
+                        const int32_t* lens, int B, int Lmax, const float* extra_embeds, const int32_t* extra_slots,
+                        int n_extra, const int32_t* resized_hw, const int32_t* orig_hw, int max_new_tokens,
+                        int eos_token_id, int64_t* out_ids, int32_t* out_lens, int32_t* out_nseg, float* out_masks,
+                        int64_t out_masks_cap, int64_t* mask_offsets, float* out_low, float* out_hidden) {
+  HIP_TRY(hipSetDevice(device_));
+  const anyref_config& c = cfg;
+  if (!finalized_) throw std::runtime_error("generate before finalize");
+  if (B <= 0 || B > c.max_batch) throw std::runtime_error("batch exceeds max_batch");
+  if (max_new_tokens < 1) throw std::runtime_error("max_new_tokens must be >= 1");
+  const int H = c.llm_dim, S = c.llm_max_seq, n_img = clip_n_;
+  const bool keep_q = c.rephrase_weight > 0.f;
+
+  clip_tower(s, clip_images, B);
+  std::vector<int> slen, img_pos;
+  const int Sp = splice_inputs(s, input_ids, lens, B, Lmax, extra_embeds, extra_slots, n_extra, slen, img_pos);
+  for (int b = 0; b < B; ++b)
+    if (slen[b] + max_new_tokens > S) throw std::runtime_error("prompt + max_new_tokens exceeds llm_max_seq");
+  llm_prefill(s, B, Sp, slen_dev_, keep_q);
+  // first token: logits of the last prompt row of every sequence
+  {
+    std::vector<int> bb(B), pp(B);
+    for (int b = 0; b < B; ++b) {
+      bb[b] = b;
+      pp[b] = slen[b] - 1;
+    }
+    HIP_TRY(hipMemcpyAsync(idx_a_, bb.data(), B * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(idx_b_, pp.data(), B * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(pos_dev_, slen.data(), B * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    launch_gather_rows(hidden_all_, S, H, idx_a_, idx_b_, B, l_xlast_, s);
+    GemvArgs h;
+    h.x = l_xlast_; h.ldx = H; h.W = lm_head_.w; h.y = l_logits_; h.ldy = c.llm_vocab; h.B = B; h.N = c.llm_vocab;
+    h.K = H;
+    launch_gemv<T>(h, s);
+    launch_argmax(l_logits_, B, c.llm_vocab, c.llm_vocab, next_dev_, s);
+  }
+  // greedy loop (HF greedy search: stop a row at EOS, pad finished rows; anyref.py:704-716)
+  std::vector<std::vector<int64_t>> gen(B);
+  std::vector<char> fin(B, 0);
+  for (int step = 0; step < max_new_tokens; ++step) {
+    HIP_TRY(hipMemcpyAsync(next_host_, next_dev_, B * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    bool all = true;
+    for (int b = 0; b < B; ++b) {
+      if (!fin[b]) {
+        gen[b].push_back(next_host_[b]);
+        if (eos_token_id >= 0 && next_host_[b] == eos_token_id) fin[b] = 1;
+      }
+      all = all && fin[b];
+    }
+    if (all || step == max_new_tokens - 1) break;
+    llm_decode_step(s, B, keep_q);
+  }
+  const int Lout = Lmax + max_new_tokens;
+  std::vector<int> seg_b, seg_pos, reph(B, 0);
+  for (int b = 0; b < B; ++b) {
+    int64_t* row = out_ids + (size_t)b * Lout;
+    for (int i = 0; i < Lout; ++i) row[i] = 0;
+    for (int i = 0; i < lens[b]; ++i) row[i] = input_ids[(size_t)b * Lmax + i];
+    for (size_t i = 0; i < gen[b].size(); ++i) row[lens[b] + i] = gen[b][i];
+    out_lens[b] = lens[b] + (int)gen[b].size();
+    // [SEG] search in output_ids[:,1:] (anyref.py:723-726); hidden row = p + n_img - 1 (the "+255")
+    const int shift = img_pos[b] >= 0 ? n_img - 1 : 0;
+    for (int p = 0; p + 1 < out_lens[b]; ++p) {
+      const int64_t id = row[p + 1];
+      if (id >= c.seg_lo && id <= c.seg_hi) {
+        const int hp = p + shift;
+        if (hp >= slen[b] + (int)gen[b].size() - 1) continue;  // no hidden state past the last forward
+        seg_b.push_back(b);
+        seg_pos.push_back(hp);
+      }
+    }
+    reph[b] = lens[b] - 1 + shift;  // input_ids[i,1:].shape[0] + 255 (anyref.py:745)
+  }
+  run_tail(s, sam_images, B, seg_b, seg_pos, reph, resized_hw, orig_hw, out_nseg, out_masks, out_masks_cap,
+           mask_offsets, out_low);
+  if (out_hidden)
+    HIP_TRY(hipMemcpyAsync(out_hidden, hidden_all_, (size_t)B * S * H * 4, hipMemcpyDeviceToDevice, s));
+}
+
+template <typename T>
+void Model<T>::forward_teacher(hipStream_t s, const float* clip_images, const float* sam_images,
+                               const int64_t* input_ids, const int32_t* lens, int B, int Lmax,
+                               const float* extra_embeds, const int32_t* extra_slots, int n_extra,
+                               const int32_t* rephrase_start, const int32_t* resized_hw, const int32_t* orig_hw,
+                               int32_t* out_nseg, float* out_masks, int64_t out_masks_cap, int64_t* mask_offsets,
+                               float* out_low, float* out_hidden, float* out_logits) {
+  HIP_TRY(hipSetDevice(device_));
+  const anyref_config& c = cfg;
+  if (!finalized_) throw std::runtime_error("forward before finalize");
+  if (B <= 0 || B > c.max_batch) throw std::runtime_error("batch exceeds max_batch");
+  const int H = c.llm_dim, S = c.llm_max_seq, n_img = clip_n_;
+  const bool keep_q = c.rephrase_weight > 0.f;
+  clip_tower(s, clip_images, B);
+  std::vector<int> slen, img_pos;
+  const int Sp = splice_inputs(s, input_ids, lens, B, Lmax, extra_embeds, extra_slots, n_extra, slen, img_pos);
+  llm_prefill(s, B, Sp, slen_dev_, keep_q);
+  if (out_logits) {
+    // [B, Sp, vocab] for the caller's LM loss
+    for (int b = 0; b < B; ++b) {
+      launch_convert<T>(hidden_all_ + (size_t)b * S * H, H, l_h_, H, slen[b], H, s);
+      gemm(s, l_h_, H, lm_head_, out_logits + (size_t)b * Sp * c.llm_vocab, c.llm_vocab, slen[b], ACT_NONE, true);
+    }
+  }
+  std::vector<int> seg_b, seg_pos, reph(B, 0);
+  for (int b = 0; b < B; ++b) {
+    const int shift = img_pos[b] >= 0 ? n_img - 1 : 0;
+    for (int p = 1; p < lens[b]; ++p) {  // hidden that predicted the [SEG]: pos - 1 + 255 (anyref.py:282)
+      const int64_t id = input_ids[(size_t)b * Lmax + p];
+      if (id >= c.seg_lo && id <= c.seg_hi) {
+        seg_b.push_back(b);
+        seg_pos.push_back(p - 1 + shift);
+      }
+    }
+    reph[b] = rephrase_start ? rephrase_start[b] - 1 + shift : 0;  // where(labels>0)[0][0] - 1 + 255 (anyref.py:378)
+  }
+  run_tail(s, sam_images, B, seg_b, seg_pos, reph, resized_hw, orig_hw, out_nseg, out_masks, out_masks_cap,
+           mask_offsets, out_low);
+  if (out_hidden)
+    HIP_TRY(hipMemcpyAsync(out_hidden, hidden_all_, (size_t)B * S * H * 4, hipMemcpyDeviceToDevice, s));
+}
+
+std::unique_ptr<ModelBase> make_model(const anyref_config& cfg, int device) {
+  if (cfg.mode == ANYREF_MODE_PARITY) return std::unique_ptr<ModelBase>(new Model<float>(cfg, device));
+  if (cfg.mode == ANYREF_MODE_PERF) return std::unique_ptr<ModelBase>(new Model<bf16>(cfg, device));
+  throw std::runtime_error("unknown mode");
+}
+
+}  // namespace anyref

@@ -1,0 +1,640 @@
+// Normalisation, data-movement and elementwise kernels (all HBM-bound; vectorised where the
+// layout allows, fp32 math throughout).
+#include "kernels.h"
+
+namespace anyref {
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm / RMSNorm: one wave per row, two passes over registers-cached data.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int MAXV>  // MAXV = ceil(D / 64) values per lane kept in registers
+__global__ __launch_bounds__(256) void norm_kernel(NormArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m = blockIdx.x * 4 + wave;
+  if (m >= a.M) return;
+  const int dm = a.row_map ? a.row_map[m] : m;
+  if (dm < 0) return;
+  const float* x = a.x + (int64_t)m * a.ldx;
+  float v[MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int d = lane + i * 64;
+    v[i] = d < a.D ? x[d] : 0.f;
+    s += v[i];
+  }
+  float mean = 0.f;
+  if (!a.rms) mean = wave_sum(s) / (float)a.D;
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int d = lane + i * 64;
+    const float c = d < a.D ? v[i] - mean : 0.f;
+    ss += c * c;
+  }
+  const float var = wave_sum(ss) / (float)a.D;
+  const float inv = a.rms ? rsqrtf(var + a.eps) : 1.f / sqrtf(var + a.eps);
+  float* yf = reinterpret_cast<float*>(a.y) + (int64_t)dm * a.ldy;
+  T* yt = reinterpret_cast<T*>(a.y) + (int64_t)dm * a.ldy;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int d = lane + i * 64;
+    if (d >= a.D) continue;
+    float o = (v[i] - mean) * inv * a.gain[d];
+    if (a.bias) o += a.bias[d];
+    o = apply_act(o, a.act);
+    if (a.y_f32)
+      yf[d] = o;
+    else
+      yt[d] = from_f32<T>(o);
+  }
+}
+
+template <typename T>
+void launch_norm(const NormArgs& a, hipStream_t s) {
+  if (a.M <= 0) return;
+  dim3 grid(cdiv(a.M, 4)), block(256);
+  const int nv = cdiv(a.D, 64);
+  if (nv <= 1)
+    hipLaunchKernelGGL((norm_kernel<T, 1>), grid, block, 0, s, a);
+  else if (nv <= 4)
+    hipLaunchKernelGGL((norm_kernel<T, 4>), grid, block, 0, s, a);
+  else if (nv <= 16)
+    hipLaunchKernelGGL((norm_kernel<T, 16>), grid, block, 0, s, a);
+  else if (nv <= 32)
+    hipLaunchKernelGGL((norm_kernel<T, 32>), grid, block, 0, s, a);
+  else if (nv <= 80)
+    hipLaunchKernelGGL((norm_kernel<T, 80>), grid, block, 0, s, a);
+  else
+    throw std::runtime_error("norm: D > 5120 not supported");
+}
+template void launch_norm<float>(const NormArgs&, hipStream_t);
+template void launch_norm<bf16>(const NormArgs&, hipStream_t);
+
+// ---------------------------------------------------------------------------------------------
+// im2col
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void im2col_patch_kernel(const float* __restrict__ img, int B, int S, int p, T* __restrict__ out,
+                                    int Kp) {
+  const int g = S / p;
+  const int64_t total = (int64_t)B * g * g * Kp;
+  const int K = 3 * p * p;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(i % Kp);
+    const int64_t row = i / Kp;
+    float v = 0.f;
+    if (k < K) {
+      const int px = (int)(row % g), py = (int)((row / g) % g), b = (int)(row / ((int64_t)g * g));
+      const int kx = k % p, ky = (k / p) % p, c = k / (p * p);
+      v = img[(((int64_t)b * 3 + c) * S + (py * p + ky)) * S + px * p + kx];
+    }
+    out[i] = from_f32<T>(v);
+  }
+}
+template <typename T>
+void launch_im2col_patch(const float* img, int B, int S, int p, void* out, int Kp, hipStream_t s) {
+  const int g = S / p;
+  const int64_t total = (int64_t)B * g * g * Kp;
+  const int grid = (int)(cdiv64(total, 256) < 4096 ? cdiv64(total, 256) : 4096);
+  hipLaunchKernelGGL((im2col_patch_kernel<T>), dim3(grid), dim3(256), 0, s, img, B, S, p,
+                     reinterpret_cast<T*>(out), Kp);
+}
+template void launch_im2col_patch<float>(const float*, int, int, int, void*, int, hipStream_t);
+template void launch_im2col_patch<bf16>(const float*, int, int, int, void*, int, hipStream_t);
+
+template <typename T>
+__global__ void im2col_3x3_kernel(const T* __restrict__ in, int B, int g, int C, T* __restrict__ out) {
+  // one thread per (row, tap, c)
+  const int64_t total = (int64_t)B * g * g * 9 * C;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const int tap = (int)((i / C) % 9);
+    const int64_t row = i / (9 * (int64_t)C);
+    const int x = (int)(row % g), y = (int)((row / g) % g), b = (int)(row / ((int64_t)g * g));
+    const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+    T v = from_f32<T>(0.f);
+    if (yy >= 0 && yy < g && xx >= 0 && xx < g) v = in[(((int64_t)b * g + yy) * g + xx) * C + c];
+    out[i] = v;
+  }
+}
+template <typename T>
+void launch_im2col_3x3(const void* in, int B, int g, int C, void* out, hipStream_t s) {
+  const int64_t total = (int64_t)B * g * g * 9 * C;
+  const int grid = (int)(cdiv64(total, 256) < 8192 ? cdiv64(total, 256) : 8192);
+  hipLaunchKernelGGL((im2col_3x3_kernel<T>), dim3(grid), dim3(256), 0, s, reinterpret_cast<const T*>(in), B,
+                     g, C, reinterpret_cast<T*>(out));
+}
+template void launch_im2col_3x3<float>(const void*, int, int, int, void*, hipStream_t);
+template void launch_im2col_3x3<bf16>(const void*, int, int, int, void*, hipStream_t);
+
+// ---------------------------------------------------------------------------------------------
+// converts / adds
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void convert_kernel(const float* __restrict__ in, int64_t ld_in, T* __restrict__ out,
+                               int64_t ld_out, int rows, int cols) {
+  const int64_t total = (int64_t)rows * cols;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cols, c = i % cols;
+    out[r * ld_out + c] = from_f32<T>(in[r * ld_in + c]);
+  }
+}
+template <typename T>
+void launch_convert(const float* in, int64_t ld_in, void* out, int64_t ld_out, int rows, int cols,
+                    hipStream_t s) {
+  const int64_t total = (int64_t)rows * cols;
+  if (total <= 0) return;
+  const int grid = (int)(cdiv64(total, 256) < 8192 ? cdiv64(total, 256) : 8192);
+  hipLaunchKernelGGL((convert_kernel<T>), dim3(grid), dim3(256), 0, s, in, ld_in, reinterpret_cast<T*>(out),
+                     ld_out, rows, cols);
+}
+template void launch_convert<float>(const float*, int64_t, void*, int64_t, int, int, hipStream_t);
+template void launch_convert<bf16>(const float*, int64_t, void*, int64_t, int, int, hipStream_t);
+
+template <typename T>
+__global__ void add_rows_kernel(const float* __restrict__ a, const float* __restrict__ b, int bmod,
+                                T* __restrict__ out, int M, int D) {
+  const int64_t total = (int64_t)M * D;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = i / D;
+    const int d = (int)(i % D);
+    out[i] = from_f32<T>(a[i] + b[(m % bmod) * D + d]);
+  }
+}
+void launch_add_rows(const float* a, const float* b, int bmod, float* out, int M, int D, hipStream_t s) {
+  const int64_t total = (int64_t)M * D;
+  if (total <= 0) return;
+  const int grid = (int)(cdiv64(total, 256) < 8192 ? cdiv64(total, 256) : 8192);
+  hipLaunchKernelGGL((add_rows_kernel<float>), dim3(grid), dim3(256), 0, s, a, b, bmod, out, M, D);
+}
+template <typename T>
+void launch_add_rows_to(const float* a, const float* b, int bmod, void* out, int M, int D, hipStream_t s) {
+  const int64_t total = (int64_t)M * D;
+  if (total <= 0) return;
+  const int grid = (int)(cdiv64(total, 256) < 8192 ? cdiv64(total, 256) : 8192);
+  hipLaunchKernelGGL((add_rows_kernel<T>), dim3(grid), dim3(256), 0, s, a, b, bmod, reinterpret_cast<T*>(out),
+                     M, D);
+}
+template void launch_add_rows_to<float>(const float*, const float*, int, void*, int, int, hipStream_t);
+template void launch_add_rows_to<bf16>(const float*, const float*, int, void*, int, int, hipStream_t);
+
+__global__ void add_vec_kernel(const float* __restrict__ a, const float* __restrict__ v, float* __restrict__ out,
+                               int M, int D) {
+  const int64_t total = (int64_t)M * D;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = a[i] + v[i % D];
+}
+void launch_add_vec(const float* a, const float* v, float* out, int M, int D, hipStream_t s) {
+  const int64_t total = (int64_t)M * D;
+  if (total <= 0) return;
+  const int grid = (int)(cdiv64(total, 256) < 8192 ? cdiv64(total, 256) : 8192);
+  hipLaunchKernelGGL(add_vec_kernel, dim3(grid), dim3(256), 0, s, a, v, out, M, D);
+}
+
+__global__ void clip_assemble_kernel(const float* __restrict__ patch, const float* __restrict__ cls,
+                                     const float* __restrict__ pos, float* __restrict__ x, int B, int n, int D) {
+  const int64_t total = (int64_t)B * (n + 1) * D;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int d = (int)(i % D);
+    const int t = (int)((i / D) % (n + 1));
+    const int b = (int)(i / ((int64_t)D * (n + 1)));
+    const float v = t == 0 ? cls[d] : patch[((int64_t)b * n + (t - 1)) * D + d];
+    x[i] = v + pos[(int64_t)t * D + d];
+  }
+}
+void launch_clip_assemble(const float* patch, const float* cls, const float* pos, float* x, int B, int n, int D,
+                          hipStream_t s) {
+  const int64_t total = (int64_t)B * (n + 1) * D;
+  const int grid = (int)(cdiv64(total, 256) < 8192 ? cdiv64(total, 256) : 8192);
+  hipLaunchKernelGGL(clip_assemble_kernel, dim3(grid), dim3(256), 0, s, patch, cls, pos, x, B, n, D);
+}
+
+// ---------------------------------------------------------------------------------------------
+// token embedding gather + image splice.  One block per output row.
+// ---------------------------------------------------------------------------------------------
+__global__ void embed_splice_kernel(const int64_t* __restrict__ ids, const int* __restrict__ lens, int B,
+                                    int Lmax, const void* __restrict__ table, int is_bf16, int vocab,
+                                    const float* __restrict__ img_feat, int n_img, float* __restrict__ x,
+                                    int Smax, int D, int* __restrict__ out_len) {
+  const int b = blockIdx.y, srow = blockIdx.x;
+  const int L = lens[b];
+  const int64_t* row = ids + (int64_t)b * Lmax;
+  // position of the (single) image placeholder, -1 if none
+  __shared__ int ip_s;
+  if (threadIdx.x == 0) {
+    int ip = -1;
+    for (int i = 0; i < L; ++i)
+      if (row[i] == -200) {
+        ip = i;
+        break;
+      }
+    ip_s = ip;
+    if (srow == 0) out_len[b] = ip >= 0 ? L + n_img - 1 : L;
+  }
+  __syncthreads();
+  const int ip = ip_s;
+  const int S = ip >= 0 ? L + n_img - 1 : L;
+  float* dst = x + ((int64_t)b * Smax + srow) * D;
+  if (srow >= S) return;
+  if (ip >= 0 && srow >= ip && srow < ip + n_img) {
+    const float* src = img_feat + ((int64_t)b * n_img + (srow - ip)) * D;
+    for (int d = threadIdx.x; d < D; d += blockDim.x) dst[d] = src[d];
+    return;
+  }
+  const int tpos = (ip >= 0 && srow >= ip + n_img) ? srow - n_img + 1 : srow;
+  int64_t id = row[tpos];
+  if (id < 0 || id >= vocab) {  // other placeholders: rows are overwritten by scatter_rows
+    for (int d = threadIdx.x; d < D; d += blockDim.x) dst[d] = 0.f;
+    return;
+  }
+  if (is_bf16) {
+    const bf16* src = reinterpret_cast<const bf16*>(table) + id * D;
+    for (int d = threadIdx.x; d < D; d += blockDim.x) dst[d] = bf2f(src[d]);
+  } else {
+    const float* src = reinterpret_cast<const float*>(table) + id * D;
+    for (int d = threadIdx.x; d < D; d += blockDim.x) dst[d] = src[d];
+  }
+}
+void launch_embed_splice(const int64_t* ids, const int* lens, int B, int Lmax, const void* emb_table,
+                         int emb_is_bf16, int vocab, const float* img_feat, int n_img, float* x, int Smax, int D,
+                         int* out_len, hipStream_t s) {
+  dim3 grid(Lmax + n_img, B);
+  if ((int)grid.x > Smax) grid.x = Smax;
+  hipLaunchKernelGGL(embed_splice_kernel, grid, dim3(256), 0, s, ids, lens, B, Lmax, emb_table, emb_is_bf16,
+                     vocab, img_feat, n_img, x, Smax, D, out_len);
+}
+
+__global__ void scatter_rows_kernel(const float* __restrict__ rows, const int* __restrict__ db,
+                                    const int* __restrict__ dp, float* __restrict__ x, int Smax, int D) {
+  const int i = blockIdx.x;
+  float* dst = x + ((int64_t)db[i] * Smax + dp[i]) * D;
+  const float* src = rows + (int64_t)i * D;
+  for (int d = threadIdx.x; d < D; d += blockDim.x) dst[d] = src[d];
+}
+void launch_scatter_rows(const float* rows, const int* dst_b, const int* dst_pos, int n, float* x, int Smax,
+                         int D, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(scatter_rows_kernel, dim3(n), dim3(256), 0, s, rows, dst_b, dst_pos, x, Smax, D);
+}
+
+__global__ void gather_rows_kernel(const float* __restrict__ x, int Smax, int D, const int* __restrict__ b,
+                                   const int* __restrict__ pos, float* __restrict__ out) {
+  const int i = blockIdx.x;
+  const float* src = x + ((int64_t)b[i] * Smax + pos[i]) * D;
+  for (int d = threadIdx.x; d < D; d += blockDim.x) out[(int64_t)i * D + d] = src[d];
+}
+void launch_gather_rows(const float* x, int Smax, int D, const int* b, const int* pos, int n, float* out,
+                        hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(n), dim3(256), 0, s, x, Smax, D, b, pos, out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// RoPE (HF rotate_half form) + KV-cache append
+// ---------------------------------------------------------------------------------------------
+template <typename T, typename TIN>
+__global__ void rope_cache_kernel(const TIN* __restrict__ qkv, int B, int S, int H, int hd,
+                                  const int* __restrict__ pos0, const int* __restrict__ lens,
+                                  const float* __restrict__ cs_tab, T* __restrict__ q_out, T* __restrict__ kc,
+                                  T* __restrict__ vc, int maxS, T* __restrict__ q_keep) {
+  // one block per (row, b); threads over (h, d < hd/2)
+  const int srow = blockIdx.x, b = blockIdx.y;
+  if (lens && srow >= lens[b]) return;
+  const int pos = (pos0 ? pos0[b] : 0) + srow;
+  const int half = hd / 2;
+  const TIN* base = qkv + ((int64_t)b * S + srow) * 3 * H * hd;
+  for (int i = threadIdx.x; i < H * half; i += blockDim.x) {
+    const int h = i / half, d = i % half;
+    // host-built table [maxS][2][hd/2] (cos | sin), same fp32 op order as HF's rotary embedding
+    const float cs = cs_tab[((int64_t)pos * 2) * half + d], sn = cs_tab[((int64_t)pos * 2 + 1) * half + d];
+    const float q1 = to_f32<TIN>(base[h * hd + d]), q2 = to_f32<TIN>(base[h * hd + d + half]);
+    const float k1 = to_f32<TIN>(base[(H + h) * hd + d]), k2 = to_f32<TIN>(base[(H + h) * hd + d + half]);
+    const float v1 = to_f32<TIN>(base[(2 * H + h) * hd + d]),
+                v2 = to_f32<TIN>(base[(2 * H + h) * hd + d + half]);
+    T* qo = q_out + (((int64_t)b * S + srow) * H + h) * hd;
+    qo[d] = from_f32<T>(q1 * cs - q2 * sn);
+    qo[d + half] = from_f32<T>(q2 * cs + q1 * sn);
+    const int64_t co = (((int64_t)b * maxS + pos) * H + h) * hd;
+    if (q_keep) {
+      q_keep[co + d] = qo[d];
+      q_keep[co + d + half] = qo[d + half];
+    }
+    kc[co + d] = from_f32<T>(k1 * cs - k2 * sn);
+    kc[co + d + half] = from_f32<T>(k2 * cs + k1 * sn);
+    vc[co + d] = from_f32<T>(v1);
+    vc[co + d + half] = from_f32<T>(v2);
+  }
+}
+template <typename T>
+void launch_rope_cache(const void* qkv, int B, int S, int H, int hd, const int* pos0, const int* lens,
+                       const float* cs_tab, void* q_out, void* kc, void* vc, int maxS, void* q_keep,
+                       hipStream_t s) {
+  hipLaunchKernelGGL((rope_cache_kernel<T, T>), dim3(S, B), dim3(256), 0, s, reinterpret_cast<const T*>(qkv), B,
+                     S, H, hd, pos0, lens, cs_tab, reinterpret_cast<T*>(q_out), reinterpret_cast<T*>(kc),
+                     reinterpret_cast<T*>(vc), maxS, reinterpret_cast<T*>(q_keep));
+}
+template void launch_rope_cache<float>(const void*, int, int, int, int, const int*, const int*, const float*,
+                                       void*, void*, void*, int, void*, hipStream_t);
+template void launch_rope_cache<bf16>(const void*, int, int, int, int, const int*, const int*, const float*,
+                                      void*, void*, void*, int, void*, hipStream_t);
+template <typename T>
+void launch_rope_cache_f32(const float* qkv, int B, int H, int hd, const int* pos, const float* cs_tab,
+                           void* q_out, void* kc, void* vc, int maxS, void* q_keep, hipStream_t s) {
+  hipLaunchKernelGGL((rope_cache_kernel<T, float>), dim3(1, B), dim3(256), 0, s, qkv, B, 1, H, hd, pos, nullptr,
+                     cs_tab, reinterpret_cast<T*>(q_out), reinterpret_cast<T*>(kc), reinterpret_cast<T*>(vc),
+                     maxS, reinterpret_cast<T*>(q_keep));
+}
+template void launch_rope_cache_f32<float>(const float*, int, int, int, const int*, const float*, void*, void*,
+                                           void*, int, void*, hipStream_t);
+template void launch_rope_cache_f32<bf16>(const float*, int, int, int, const int*, const float*, void*, void*,
+                                          void*, int, void*, hipStream_t);
+
+__global__ void embed_rows_kernel(const int64_t* __restrict__ ids, const void* __restrict__ table, int is_bf16,
+                                  int D, float* __restrict__ x) {
+  const int b = blockIdx.x;
+  const int64_t id = ids[b];
+  if (is_bf16) {
+    const bf16* src = reinterpret_cast<const bf16*>(table) + id * D;
+    for (int d = threadIdx.x; d < D; d += blockDim.x) x[(int64_t)b * D + d] = bf2f(src[d]);
+  } else {
+    const float* src = reinterpret_cast<const float*>(table) + id * D;
+    for (int d = threadIdx.x; d < D; d += blockDim.x) x[(int64_t)b * D + d] = src[d];
+  }
+}
+void launch_embed_rows(const int64_t* ids, int B, const void* table, int is_bf16, int D, float* x,
+                       hipStream_t s) {
+  hipLaunchKernelGGL(embed_rows_kernel, dim3(B), dim3(256), 0, s, ids, table, is_bf16, D, x);
+}
+__global__ void decode_index_kernel(const int* __restrict__ pos, int B, int maxS, int* __restrict__ row_map,
+                                    int* __restrict__ kvlen) {
+  const int b = threadIdx.x;
+  if (b < B) {
+    row_map[b] = b * maxS + pos[b];
+    kvlen[b] = pos[b] + 1;
+  }
+}
+void launch_decode_index(const int* pos, int B, int maxS, int* row_map, int* kvlen, hipStream_t s) {
+  hipLaunchKernelGGL(decode_index_kernel, dim3(1), dim3(64), 0, s, pos, B, maxS, row_map, kvlen);
+}
+__global__ void build_tokens_kernel(const float* __restrict__ out_tokens, int n_out, const float* __restrict__ pred,
+                                    int C, float* __restrict__ tokens) {
+  const int i = blockIdx.y, t = blockIdx.x;
+  const float* src = t < n_out ? out_tokens + (int64_t)t * C : pred + (int64_t)i * C;
+  float* dst = tokens + ((int64_t)i * (n_out + 1) + t) * C;
+  for (int d = threadIdx.x; d < C; d += blockDim.x) dst[d] = src[d];
+}
+void launch_build_tokens(const float* out_tokens, int n_out, const float* pred, int n, int C, float* tokens,
+                         hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(build_tokens_kernel, dim3(n_out + 1, n), dim3(256), 0, s, out_tokens, n_out, pred, C, tokens);
+}
+
+template <typename T>
+__global__ void swiglu_kernel(const T* __restrict__ gu, int M, int F, T* __restrict__ out) {
+  const int64_t total = (int64_t)M * F;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = i / F;
+    const int j = (int)(i % F);
+    const float g = to_f32<T>(gu[m * 2 * F + j]), u = to_f32<T>(gu[m * 2 * F + F + j]);
+    out[i] = from_f32<T>(apply_act(g, ACT_SILU) * u);
+  }
+}
+template <typename T>
+void launch_swiglu(const void* gu, int M, int F, void* out, hipStream_t s) {
+  const int64_t total = (int64_t)M * F;
+  if (total <= 0) return;
+  const int grid = (int)(cdiv64(total, 256) < 8192 ? cdiv64(total, 256) : 8192);
+  hipLaunchKernelGGL((swiglu_kernel<T>), dim3(grid), dim3(256), 0, s, reinterpret_cast<const T*>(gu), M, F,
+                     reinterpret_cast<T*>(out));
+}
+template void launch_swiglu<float>(const void*, int, int, void*, hipStream_t);
+template void launch_swiglu<bf16>(const void*, int, int, void*, hipStream_t);
+
+// argmax, first index on ties (torch.argmax on CPU returns the first maximal index)
+__global__ void argmax_kernel(const float* __restrict__ x, int N, int ldx, int64_t* __restrict__ out) {
+  const float* row = x + (int64_t)blockIdx.x * ldx;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int i = threadIdx.x; i < N; i += blockDim.x) {
+    const float v = row[i];
+    if (v > best || (v == best && i < bi)) {
+      best = v;
+      bi = i;
+    }
+  }
+  __shared__ float sv[256];
+  __shared__ int si[256];
+  sv[threadIdx.x] = best;
+  si[threadIdx.x] = bi;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      const float v = sv[threadIdx.x + o];
+      const int i = si[threadIdx.x + o];
+      if (v > sv[threadIdx.x] || (v == sv[threadIdx.x] && i < si[threadIdx.x])) {
+        sv[threadIdx.x] = v;
+        si[threadIdx.x] = i;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[blockIdx.x] = si[0];
+}
+void launch_argmax(const float* x, int M, int N, int ldx, int64_t* out, hipStream_t s) {
+  if (M <= 0) return;
+  hipLaunchKernelGGL(argmax_kernel, dim3(M), dim3(256), 0, s, x, N, ldx, out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// mask-decoder upscaler tails
+// ---------------------------------------------------------------------------------------------
+// One wave per output pixel: un-shuffle ConvT(k2,s2) GEMM output, LayerNorm2d over C, GELU.
+template <typename T>
+__global__ __launch_bounds__(256) void upscale1_kernel(const float* __restrict__ tmp, int n, int g, int C,
+                                                       const float* __restrict__ ln_g,
+                                                       const float* __restrict__ ln_b, float eps,
+                                                       T* __restrict__ out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t pix = (int64_t)blockIdx.x * 4 + wave;  // over n * 2g * 2g
+  const int G = 2 * g;
+  if (pix >= (int64_t)n * G * G) return;
+  const int X = (int)(pix % G), Y = (int)((pix / G) % G), i = (int)(pix / ((int64_t)G * G));
+  const float* src = tmp + (((int64_t)i * g + Y / 2) * g + X / 2) * 4 * C + ((Y & 1) * 2 + (X & 1)) * C;
+  // C <= 128: up to two values per lane
+  float v0 = lane < C ? src[lane] : 0.f, v1 = lane + 64 < C ? src[lane + 64] : 0.f;
+  const float mean = wave_sum(v0 + v1) / (float)C;
+  const float c0 = lane < C ? v0 - mean : 0.f, c1 = lane + 64 < C ? v1 - mean : 0.f;
+  const float var = wave_sum(c0 * c0 + c1 * c1) / (float)C;
+  const float inv = 1.f / sqrtf(var + eps);
+  T* dst = out + pix * C;
+  if (lane < C) dst[lane] = from_f32<T>(apply_act(c0 * inv * ln_g[lane] + ln_b[lane], ACT_GELU));
+  if (lane + 64 < C) dst[lane + 64] = from_f32<T>(apply_act(c1 * inv * ln_g[lane + 64] + ln_b[lane + 64], ACT_GELU));
+}
+template <typename T>
+void launch_upscale1(const float* tmp, int n, int g, int C, const float* ln_g, const float* ln_b, float eps,
+                     void* out, hipStream_t s) {
+  if (C > 128) throw std::runtime_error("upscale1: C > 128");
+  const int64_t pix = (int64_t)n * 4 * g * g;
+  hipLaunchKernelGGL((upscale1_kernel<T>), dim3((unsigned)cdiv64(pix, 4)), dim3(256), 0, s, tmp, n, g, C, ln_g,
+                     ln_b, eps, reinterpret_cast<T*>(out));
+}
+template void launch_upscale1<float>(const float*, int, int, int, const float*, const float*, float, void*,
+                                     hipStream_t);
+template void launch_upscale1<bf16>(const float*, int, int, int, const float*, const float*, float, void*,
+                                    hipStream_t);
+
+// masks[i,t,Y,X] = sum_c hyper[i,t,c] * gelu(tmp[i, (Y/2,X/2), (Y%2*2+X%2)*C + c]); thread per pixel.
+__global__ void upscale2_masks_kernel(const float* __restrict__ tmp, const float* __restrict__ hyper, int n,
+                                      int ntok, int g2, int C, float* __restrict__ masks) {
+  extern __shared__ float hs[];  // [ntok*C] of prompt i
+  const int i = blockIdx.y;
+  for (int j = threadIdx.x; j < ntok * C; j += blockDim.x) hs[j] = hyper[(int64_t)i * ntok * C + j];
+  __syncthreads();
+  const int G = 2 * g2;
+  const int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= (int64_t)G * G) return;
+  const int X = (int)(pix % G), Y = (int)(pix / G);
+  const float* src = tmp + (((int64_t)i * g2 + Y / 2) * g2 + X / 2) * 4 * C + ((Y & 1) * 2 + (X & 1)) * C;
+  float acc[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) acc[t] = 0.f;
+  for (int c = 0; c < C; ++c) {
+    const float u = apply_act(src[c], ACT_GELU);
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+      if (t < ntok) acc[t] = fmaf(hs[t * C + c], u, acc[t]);
+  }
+  for (int t = 0; t < ntok; ++t) masks[(((int64_t)i * ntok + t) * G + Y) * G + X] = acc[t];
+}
+void launch_upscale2_masks(const float* tmp, const float* hyper, int n, int ntok, int g2, int C, float* masks,
+                           hipStream_t s) {
+  if (ntok > 8) throw std::runtime_error("upscale2: more than 8 mask tokens");
+  const int G = 2 * g2;
+  dim3 grid((unsigned)cdiv64((int64_t)G * G, 256), n);
+  hipLaunchKernelGGL(upscale2_masks_kernel, grid, dim3(256), ntok * C * sizeof(float), s, tmp, hyper, n, ntok,
+                     g2, C, masks);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sam.postprocess_masks: bilinear(lh x lw -> S x S), crop [:rh,:rw], bilinear -> (H,W).
+// PyTorch upsample_bilinear2d, align_corners=False: src = max(scale*(dst+0.5)-0.5, 0),
+// i0 = floor(src), i1 = min(i0+1, in-1), lambda = src - i0; scale = in/out in fp32.
+// ---------------------------------------------------------------------------------------------
+__device__ inline void bil_idx(int dst, float scale, int in, int& i0, int& i1, float& l1) {
+  float src = scale * ((float)dst + 0.5f) - 0.5f;
+  if (src < 0.f) src = 0.f;
+  i0 = (int)src;
+  if (i0 > in - 1) i0 = in - 1;
+  i1 = i0 < in - 1 ? i0 + 1 : i0;
+  l1 = src - (float)i0;
+}
+__device__ inline float bil_stage1(const float* __restrict__ low, int lh, int lw, float sy, float sx, int y,
+                                   int x) {
+  int y0, y1, x0, x1;
+  float ly, lx;
+  bil_idx(y, sy, lh, y0, y1, ly);
+  bil_idx(x, sx, lw, x0, x1, lx);
+  const float a = low[y0 * lw + x0], b = low[y0 * lw + x1], c = low[y1 * lw + x0], d = low[y1 * lw + x1];
+  return (1.f - ly) * ((1.f - lx) * a + lx * b) + ly * ((1.f - lx) * c + lx * d);
+}
+__global__ void postprocess_kernel(const float* __restrict__ low, int64_t lstride, int lh, int lw, int S, int rh,
+                                   int rw, int H, int W, float* __restrict__ out) {
+  const int i = blockIdx.y;
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= (int64_t)H * W) return;
+  const int X = (int)(p % W), Y = (int)(p / W);
+  const float* l = low + (int64_t)i * lstride;
+  const float s1y = (float)lh / (float)S, s1x = (float)lw / (float)S;
+  const float s2y = (float)rh / (float)H, s2x = (float)rw / (float)W;
+  int y0, y1, x0, x1;
+  float ly, lx;
+  bil_idx(Y, s2y, rh, y0, y1, ly);
+  bil_idx(X, s2x, rw, x0, x1, lx);
+  const float a = bil_stage1(l, lh, lw, s1y, s1x, y0, x0), b = bil_stage1(l, lh, lw, s1y, s1x, y0, x1);
+  const float c = bil_stage1(l, lh, lw, s1y, s1x, y1, x0), d = bil_stage1(l, lh, lw, s1y, s1x, y1, x1);
+  out[(int64_t)i * H * W + p] = (1.f - ly) * ((1.f - lx) * a + lx * b) + ly * ((1.f - lx) * c + lx * d);
+}
+void launch_postprocess(const float* low, int64_t lstride, int n, int lh, int lw, int S, int rh, int rw, int H,
+                        int W, float* out, hipStream_t s) {
+  if (n <= 0) return;
+  dim3 grid((unsigned)cdiv64((int64_t)H * W, 256), n);
+  hipLaunchKernelGGL(postprocess_kernel, grid, dim3(256), 0, s, low, lstride, lh, lw, S, rh, rw, H, W, out);
+}
+
+// dense PE: out[(y*g+x), f] = sin(2pi*(cx*G[0,f] + cy*G[1,f])), out[.., F+f] = cos(..); c = 2*((i+.5)/g)-1
+__global__ void dense_pe_kernel(const float* __restrict__ gauss, int g, int F, float* __restrict__ out) {
+  const int64_t total = (int64_t)g * g * F;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int f = (int)(i % F);
+    const int x = (int)((i / F) % g), y = (int)(i / ((int64_t)F * g));
+    const float cx = 2.f * (((float)x + 0.5f) / (float)g) - 1.f, cy = 2.f * (((float)y + 0.5f) / (float)g) - 1.f;
+    const float v = 6.283185307179586f * (cx * gauss[f] + cy * gauss[F + f]);
+    out[((int64_t)y * g + x) * 2 * F + f] = sinf(v);
+    out[((int64_t)y * g + x) * 2 * F + F + f] = cosf(v);
+  }
+}
+void launch_dense_pe(const float* gauss, int g, int F, float* out, hipStream_t s) {
+  const int64_t total = (int64_t)g * g * F;
+  hipLaunchKernelGGL(dense_pe_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, s, gauss, g, F, out);
+}
+
+__global__ void fill_i32_kernel(int* p, int v, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+void launch_fill_i32(int* p, int v, int n, hipStream_t s) {
+  hipLaunchKernelGGL(fill_i32_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, p, v, n);
+}
+__global__ void add_i32_kernel(int* p, int v, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] += v;
+}
+void launch_add_i32(int* p, int v, int n, hipStream_t s) {
+  hipLaunchKernelGGL(add_i32_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, p, v, n);
+}
+
+// y[:] += w * sum_{j in [s0,e0)} (p[j]/sum p) * X[j,:]
+__global__ void rephrase_kernel(const float* __restrict__ hidden, int D, const float* __restrict__ attn, int s0,
+                                int e0, float weight, float* __restrict__ y) {
+  float tot = 0.f;
+  for (int j = s0; j < e0; ++j) tot += attn[j];
+  for (int d = blockIdx.x * blockDim.x + threadIdx.x; d < D; d += gridDim.x * blockDim.x) {
+    float acc = 0.f;
+    for (int j = s0; j < e0; ++j) acc += hidden[(int64_t)j * D + d] * (attn[j] / tot);
+    y[d] += weight * acc;
+  }
+}
+void launch_rephrase(const float* hidden_b, int D, const float* attn_row, int s0, int e0, float weight, float* y,
+                     hipStream_t s) {
+  hipLaunchKernelGGL(rephrase_kernel, dim3(cdiv(D, 256)), dim3(256), 0, s, hidden_b, D, attn_row, s0, e0, weight,
+                     y);
+}
+
+__global__ void to_f32_kernel(const void* __restrict__ in, int dtype, float* __restrict__ out, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float v;
+    if (dtype == 0)
+      v = reinterpret_cast<const float*>(in)[i];
+    else if (dtype == 1)
+      v = bf2f(reinterpret_cast<const bf16*>(in)[i]);
+    else
+      v = (float)reinterpret_cast<const _Float16*>(in)[i];
+    out[i] = v;
+  }
+}
+void launch_to_f32(const void* in, int dtype, float* out, int64_t n, hipStream_t s) {
+  if (n <= 0) return;
+  const int grid = (int)(cdiv64(n, 256) < 16384 ? cdiv64(n, 256) : 16384);
+  hipLaunchKernelGGL(to_f32_kernel, dim3(grid), dim3(256), 0, s, in, dtype, out, n);
+}
+
+}  // namespace anyref

@@ -1,0 +1,89 @@
+// Kernel-level C entry points for the parity tests (include/anyref_hip_ops.h).
+#include <string>
+
+#include "../../include/anyref_hip_ops.h"
+#include "kernels.h"
+
+using namespace anyref;
+
+static thread_local std::string g_op_err;
+
+#define OP_GUARD(body)                                   \
+  try {                                                  \
+    body;                                                \
+    hipError_t _e = hipGetLastError();                   \
+    if (_e != hipSuccess) {                              \
+      g_op_err = std::string("HIP error: ") + hipGetErrorString(_e); \
+      return 3;                                          \
+    }                                                    \
+    return 0;                                            \
+  } catch (const std::exception& e) {                    \
+    g_op_err = e.what();                                 \
+    return 2;                                            \
+  }
+
+extern "C" {
+
+const char* anyref_op_last_error(void) { return g_op_err.c_str(); }
+
+int anyref_op_gemm(int t, void* stream, const void* A, const void* W, const float* bias, void* C,
+                   const float* resid, const int32_t* row_map, int M, int N, int K, int act, int c_f32) {
+  OP_GUARD({
+    GemmArgs a;
+    a.A = A; a.lda = K; a.W = W; a.ldw = K; a.bias = bias; a.C = C; a.ldc = N; a.resid = resid; a.ldr = N;
+    a.row_map = row_map; a.M = M; a.N = N; a.K = K; a.act = act; a.c_f32 = c_f32;
+    if (t == 0) launch_gemm<float>(a, (hipStream_t)stream); else launch_gemm<bf16>(a, (hipStream_t)stream);
+  });
+}
+
+int anyref_op_gemv(int t, void* stream, const float* x, const float* gain, float eps, const void* W,
+                   const void* W2, const float* bias, float* y, const float* resid, int B, int N, int K, int act) {
+  OP_GUARD({
+    GemvArgs a;
+    a.x = x; a.ldx = K; a.gain = gain; a.eps = eps; a.W = W; a.W2 = W2; a.bias = bias; a.y = y; a.resid = resid;
+    a.ldy = N; a.B = B; a.N = N; a.K = K; a.act = act;
+    if (t == 0) launch_gemv<float>(a, (hipStream_t)stream); else launch_gemv<bf16>(a, (hipStream_t)stream);
+  });
+}
+
+int anyref_op_norm(int t, void* stream, const float* x, const float* gain, const float* bias, float* y, int M,
+                   int D, float eps, int rms) {
+  OP_GUARD({
+    NormArgs a;
+    a.x = x; a.ldx = D; a.gain = gain; a.bias = bias; a.y = y; a.ldy = D; a.M = M; a.D = D; a.eps = eps;
+    a.rms = rms; a.y_f32 = 1;
+    if (t == 0) launch_norm<float>(a, (hipStream_t)stream); else launch_norm<bf16>(a, (hipStream_t)stream);
+  });
+}
+
+int anyref_op_attention(int t, void* stream, const void* q, const void* k, const void* v, void* o, int B, int H,
+                        int Sq, int Sk, int hd, float scale, int causal, const int32_t* kv_len,
+                        const float* rel_h, const float* rel_w, int kh, int kw) {
+  OP_GUARD({
+    AttnArgs a;
+    a.Q = q; a.K = k; a.V = v; a.O = o;
+    a.q_bs = (int64_t)Sq * H * hd; a.q_rs = H * hd; a.q_hs = hd;
+    a.k_bs = a.v_bs = (int64_t)Sk * H * hd; a.k_rs = a.v_rs = H * hd; a.k_hs = a.v_hs = hd;
+    a.o_bs = (int64_t)Sq * H * hd; a.o_rs = H * hd; a.o_hs = hd;
+    a.B = B; a.H = H; a.Sq = Sq; a.Sk = Sk; a.hd = hd; a.scale = scale; a.causal = causal; a.kv_len = kv_len;
+    a.rel_h = rel_h; a.rel_w = rel_w; a.kh = kh; a.kw = kw;
+    if (t == 0) launch_attention<float>(a, (hipStream_t)stream); else launch_attention<bf16>(a, (hipStream_t)stream);
+  });
+}
+
+int anyref_op_rel_pos(int t, void* stream, const void* q, const float* tab_h, const float* tab_w, int B, int H,
+                      int size, int hd, float* rel_h, float* rel_w) {
+  OP_GUARD({
+    const int64_t S = (int64_t)size * size;
+    if (t == 0)
+      launch_rel_pos<float>(q, S * H * hd, H * hd, hd, tab_h, tab_w, B, H, size, hd, rel_h, rel_w, (hipStream_t)stream);
+    else
+      launch_rel_pos<bf16>(q, S * H * hd, H * hd, hd, tab_h, tab_w, B, H, size, hd, rel_h, rel_w, (hipStream_t)stream);
+  });
+}
+
+int anyref_op_postprocess(void* stream, const float* low, int n, int lh, int lw, int S, int rh, int rw, int H, int W,
+                          float* out) {
+  OP_GUARD(launch_postprocess(low, (int64_t)lh * lw, n, lh, lw, S, rh, rw, H, W, out, (hipStream_t)stream));
+}
+}

@@ -1,0 +1,447 @@
+"""Python surface of the backend: a mirror of the reference's `AnyRefForCausalLM`
+(`model/anyref.py:182-237,647-822`) over the C-ABI library.
+
+What is preserved: the `generate(...)` and `forward(**kwargs)` signatures and
+argument meaning, the `[SEG]`-token -> SAM prompt hand-off, the state_dict weight names, the
+`.config.{eos,bos,pad}_token_id` attributes and the no-op plumbing calls the eval scripts make
+(`get_model()`, `initialize_vision_modules`, `initialize_anyref_modules`,
+`resize_token_embeddings`, `.eval()`, `.cuda()`, `.to()`, `.half()`), so
+`eval_referseg.py:137` / `eval_avs_object.py:137` can drive this class unchanged.
+
+Deviations, both deliberate:
+  * `generate` always returns the 3-tuple `(output_ids, pred_masks, (None, None, None))`; the
+    reference returns a 2-tuple on its success path (`anyref.py:822`) but both north-star callers
+    unpack three values (`eval_referseg.py:136`, `eval_avs_object.py:137`).
+  * batched calls decode every row exactly as a batch of one (per-row lengths, no left-pad
+    position shift); left-padded `input_ids` + `attention_masks` are accepted and un-padded here.
+
+PyTorch is only the owner of device memory and streams; all arithmetic runs in libanyref_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from types import SimpleNamespace
+from typing import Dict, List, Optional, Sequence
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+from .config import (AnyRefConfig, IMAGE_TOKEN_INDEX, AUDIO_REF_INDEX, IMG_REF_INDEX, AUDIO_REF_NUM)
+
+_DT = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16, torch.float16: _lib.F16}
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _c_config(cfg: AnyRefConfig, mode: int, max_batch: int, max_seg: int) -> _lib.AnyrefConfig:
+    c = _lib.AnyrefConfig()
+    c.abi_version = _lib.ABI_VERSION
+    c.mode = mode
+    cl, l, s = cfg.clip, cfg.llm, cfg.sam
+    c.clip_image, c.clip_patch, c.clip_dim, c.clip_heads = cl.image_size, cl.patch, cl.dim, cl.heads
+    c.clip_layers_run, c.clip_mlp, c.clip_eps = cl.layers_run, cl.mlp, cl.eps
+    c.llm_vocab, c.llm_dim, c.llm_heads, c.llm_layers = l.vocab, l.dim, l.heads, l.layers
+    c.llm_mlp, c.llm_max_seq, c.llm_rms_eps, c.llm_rope_theta = l.mlp, l.max_seq, l.rms_eps, l.rope_theta
+    c.sam_img, c.sam_patch, c.sam_dim, c.sam_depth = s.img_size, s.patch, s.dim, s.depth
+    c.sam_heads, c.sam_mlp_ratio, c.sam_window = s.heads, s.mlp_ratio, s.window
+    assert len(s.global_idx) <= 8
+    c.sam_n_global = len(s.global_idx)
+    for i, g in enumerate(s.global_idx):
+        c.sam_global_idx[i] = g
+    c.sam_out_chans, c.dec_heads, c.dec_mlp, c.dec_depth = s.out_chans, s.dec_heads, s.dec_mlp, s.dec_depth
+    c.num_mask_tokens = s.num_mask_tokens
+    c.out_dim, c.audio_dim = cfg.out_dim, cfg.audio_dim
+    c.seg_lo, c.seg_hi = cfg.seg_range()
+    c.rephrase_weight = float(cfg.rephrase_weight)
+    c.max_batch, c.max_seg = max_batch, max_seg
+    return c
+
+
+class AnyRefForCausalLM:
+    """MI355X-native stand-in for `model.anyref.AnyRefForCausalLM` (inference surface)."""
+
+    def __init__(self, cfg: AnyRefConfig, mode: str = "perf", device: int = 0, max_batch: int = 1,
+                 max_seg: int = 4, audio_encoder=None, **kwargs):
+        # constructor kwargs of the reference (anyref.py:188-209) that shape the path
+        if "seg_token_idx" in kwargs:
+            cfg.seg_token_idx = kwargs.pop("seg_token_idx")
+        if "rephrase_weight" in kwargs:
+            cfg.rephrase_weight = kwargs.pop("rephrase_weight")
+        if "out_dim" in kwargs:
+            cfg.out_dim = kwargs.pop("out_dim")
+        self.ce_loss_weight = kwargs.pop("ce_loss_weight", 1.0)
+        self.dice_loss_weight = kwargs.pop("dice_loss_weight", 0.5)
+        self.bce_loss_weight = kwargs.pop("bce_loss_weight", 2.0)
+        self.cfg = cfg
+        self.mode = {"parity": _lib.MODE_PARITY, "perf": _lib.MODE_PERF}[mode]
+        self.mode_name = mode
+        self.device_index = device
+        self.device = torch.device("cuda", device)
+        self.max_batch, self.max_seg = max_batch, max_seg
+        self.audio_encoder = audio_encoder      # PyTorch-ROCm ImageBind audio trunk (anyref_amd.audio)
+        self.config = SimpleNamespace(eos_token_id=cfg.eos_token_id, bos_token_id=cfg.bos_token_id,
+                                      pad_token_id=cfg.pad_token_id, hidden_size=cfg.llm.dim,
+                                      vocab_size=cfg.llm.vocab, use_cache=True)
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("AnyRefForCausalLM needs an MI355X: the HIP backend has no CPU fallback")
+        h = C.c_void_p()
+        cc = _c_config(cfg, self.mode, max_batch, max_seg)
+        rc = self.lib.anyref_create(C.byref(cc), device, C.byref(h))
+        if rc != 0:
+            raise RuntimeError("anyref_create: " + self.lib.anyref_last_error(None).decode())
+        self.h = h
+        self._finalized = False
+        self.n_img = cfg.clip.n_patches
+
+    # ---- lifetime ------------------------------------------------------------------------
+    def __del__(self):
+        h = getattr(self, "h", None)
+        if h:
+            try:
+                self.lib.anyref_destroy(h)
+            except Exception:
+                pass
+            self.h = None
+
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            raise RuntimeError(f"{what}: {self.lib.anyref_last_error(self.h).decode()}")
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ---- weights (reference state_dict names) --------------------------------------------
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = False):
+        for name, t in sd.items():
+            if t.dtype not in _DT:
+                t = t.float()
+            t = t.contiguous()
+            shape = (C.c_int64 * max(t.dim(), 1))(*t.shape)
+            self._check(self.lib.anyref_set_weight(self.h, name.encode(), _ptr(t), int(t.is_cuda), _DT[t.dtype],
+                                                   shape, t.dim()), f"set_weight({name})")
+        self._check(self.lib.anyref_finalize(self.h), "finalize")
+        self._finalized = True
+        return [], []
+
+    @classmethod
+    def from_state_dict(cls, cfg: AnyRefConfig, sd, **kw) -> "AnyRefForCausalLM":
+        m = cls(cfg, **kw)
+        m.load_state_dict(sd)
+        return m
+
+    # ---- plumbing the reference's eval scripts call (eval_referseg.py:70-88) ---------------
+    def get_model(self):
+        return self
+
+    def get_vision_tower(self):
+        return self
+
+    def initialize_vision_modules(self, *_a, **_k):
+        return None
+
+    def initialize_anyref_modules(self, *_a, **_k):
+        return None
+
+    def resize_token_embeddings(self, n: int):
+        if n != self.cfg.llm.vocab:
+            raise ValueError(f"tokenizer has {n} tokens but the backend was built for vocab {self.cfg.llm.vocab}")
+
+    def eval(self):
+        return self
+
+    def cuda(self, *_a):
+        return self
+
+    def half(self):
+        return self
+
+    def to(self, *_a, **_k):
+        return self
+
+    @property
+    def device_bytes(self) -> int:
+        return int(self.lib.anyref_device_bytes(self.h))
+
+    # ---- helpers ---------------------------------------------------------------------------
+    def _rows(self, input_ids: torch.Tensor, attention_masks: Optional[torch.Tensor]):
+        """-> (ids int64 host [B,Lmax] right-aligned rows, lens int32 [B])."""
+        ids = input_ids.detach().to("cpu", torch.long)
+        if ids.dim() == 1:
+            ids = ids[None]
+        B, Lm = ids.shape
+        rows = []
+        for b in range(B):
+            r = ids[b]
+            if attention_masks is not None:
+                r = r[attention_masks[b].to("cpu").bool()]
+            rows.append(r)
+        lens = torch.tensor([len(r) for r in rows], dtype=torch.int32)
+        out = torch.zeros(B, int(lens.max()), dtype=torch.long)
+        for b, r in enumerate(rows):
+            out[b, : len(r)] = r
+        return out.contiguous(), lens
+
+    def _extra(self, ids: torch.Tensor, lens, audios, ref_feats):
+        """Projected audio / reference features -> (extra_embeds dev [n,H], slots host [n,2])."""
+        embeds, slots = [], []
+        B = ids.shape[0]
+        if audios is not None:
+            for b in range(B):
+                a = audios[b] if isinstance(audios, (list, tuple)) else audios[b:b + 1]
+                if a is None:
+                    continue
+                if a.dim() >= 4:     # raw mel clips [1,3,1,128,204] -> ImageBind embedding [3,1024]
+                    if self.audio_encoder is None:
+                        raise RuntimeError("raw audio given but no audio_encoder attached (anyref_amd.audio)")
+                    _, emb = self.audio_encoder.get_audio_feature(a.to(self.device).float())
+                    a = emb[0]
+                a = a.to(self.device, torch.float32).reshape(-1, self.cfg.audio_dim).contiguous()
+                out = torch.empty(a.shape[0], self.cfg.llm.dim, device=self.device, dtype=torch.float32)
+                self._check(self.lib.anyref_project_audio(self.h, self._stream(), _ptr(a), a.shape[0], _ptr(out)),
+                            "project_audio")
+                pos = (ids[b, : lens[b]] == AUDIO_REF_INDEX).nonzero().flatten().tolist()
+                if len(pos) != out.shape[0]:
+                    raise ValueError(f"row {b}: {len(pos)} audio placeholders but {out.shape[0]} audio features")
+                embeds.append(out)
+                slots += [(b, p) for p in pos]
+        if ref_feats is not None:
+            for b in range(B):
+                r = ref_feats[b]
+                if r is None:
+                    continue
+                r = r.to(self.device, torch.float32).reshape(-1, self.cfg.llm.dim).contiguous()
+                pos = (ids[b, : lens[b]] == IMG_REF_INDEX).nonzero().flatten().tolist()
+                if len(pos) != r.shape[0]:
+                    raise ValueError(f"row {b}: {len(pos)} image-ref placeholders but {r.shape[0]} features")
+                embeds.append(r)
+                slots += [(b, p) for p in pos]
+        if not embeds:
+            return None, None, 0
+        e = torch.cat(embeds, 0).contiguous()
+        s = torch.tensor(slots, dtype=torch.int32).contiguous()
+        return e, s, e.shape[0]
+
+    def _ref_features(self, ref_images):
+        """`ref_images` branch (anyref.py:681-702): CLIP features pooled 256 -> 16 -> IMG_REF_NUM."""
+        if ref_images is None:
+            return None
+        from .config import IMG_REF_NUM
+        feats = []
+        items = ref_images if isinstance(ref_images, (list, tuple)) else list(ref_images)
+        for r in items:
+            if r is None:
+                feats.append(None)
+                continue
+            if r.dim() == 1:
+                raise NotImplementedError("RoI-coordinate reference (anyref.py:688-689) needs the absent llava layer")
+            f = self.encode_images(r[None].float())[0]                    # [256, H]
+            ll, c = f.shape
+            f = f.reshape(ll // 16, 16, c).mean(1)
+            if f.shape[0] != IMG_REF_NUM:
+                f = f.reshape(IMG_REF_NUM, IMG_REF_NUM, c).mean(1)
+            feats.append(f)
+        return feats
+
+    # ---- stage calls (used by tests and by callers that want the pieces) -------------------
+    def encode_images(self, clip_images: torch.Tensor, return_clip: bool = False):
+        x = clip_images.to(self.device, torch.float32).contiguous()
+        B = x.shape[0]
+        out = torch.empty(B, self.n_img, self.cfg.llm.dim, device=self.device, dtype=torch.float32)
+        cf = torch.empty(B, self.n_img, self.cfg.clip.dim, device=self.device, dtype=torch.float32) if return_clip else None
+        self._check(self.lib.anyref_encode_images(self.h, self._stream(), _ptr(x), B, _ptr(out), _ptr(cf)),
+                    "encode_images")
+        return (out, cf) if return_clip else out
+
+    def sam_encode(self, sam_images: torch.Tensor) -> torch.Tensor:
+        """-> [B, 256, g, g] (the reference's NCHW layout)."""
+        x = sam_images.to(self.device, torch.float32).contiguous()
+        B, g = x.shape[0], self.cfg.sam.grid
+        out = torch.empty(B, g * g, self.cfg.sam.out_chans, device=self.device, dtype=torch.float32)
+        self._check(self.lib.anyref_sam_encode(self.h, self._stream(), _ptr(x), B, _ptr(out)), "sam_encode")
+        return out.view(B, g, g, -1).permute(0, 3, 1, 2)
+
+    def mask_decode(self, image_embedding: torch.Tensor, pred_embeddings: torch.Tensor, resized_size=None,
+                    original_size=None):
+        """image_embedding [256,g,g] or [1,256,g,g]; pred_embeddings [n,256] ->
+        dict(masks4 [n,4,4g,4g], iou [n,4], masks [n,H,W] if sizes given)."""
+        g, Cc = self.cfg.sam.grid, self.cfg.sam.out_chans
+        e = image_embedding.reshape(Cc, g * g).t().to(self.device, torch.float32).contiguous()
+        p = pred_embeddings.to(self.device, torch.float32).reshape(-1, self.cfg.out_dim).contiguous()
+        n, nt = p.shape[0], self.cfg.sam.num_mask_tokens
+        m4 = torch.empty(n, nt, 4 * g, 4 * g, device=self.device, dtype=torch.float32)
+        iou = torch.empty(n, nt, device=self.device, dtype=torch.float32)
+        out = rs = os_ = None
+        if original_size is not None:
+            out = torch.empty(n, int(original_size[0]), int(original_size[1]), device=self.device, dtype=torch.float32)
+            rs = (C.c_int32 * 2)(int(resized_size[0]), int(resized_size[1]))
+            os_ = (C.c_int32 * 2)(int(original_size[0]), int(original_size[1]))
+        self._check(self.lib.anyref_mask_decode(self.h, self._stream(), _ptr(e), _ptr(p), n, _ptr(m4), _ptr(iou),
+                                                rs, os_, _ptr(out)), "mask_decode")
+        return dict(masks4=m4, iou=iou, masks=out)
+
+    def llm_forward(self, embeds: torch.Tensor, lens: Optional[Sequence[int]] = None, want_logits: bool = False,
+                    attn_q: Optional[Sequence[int]] = None):
+        x = embeds.to(self.device, torch.float32).contiguous()
+        B, S, H = x.shape
+        ln = (C.c_int32 * B)(*([S] * B if lens is None else [int(v) for v in lens]))
+        hidden = torch.empty(B, S, H, device=self.device, dtype=torch.float32)
+        logits = torch.empty(B, S, self.cfg.llm.vocab, device=self.device, dtype=torch.float32) if want_logits else None
+        aq = ar = None
+        if attn_q is not None:
+            aq = (C.c_int32 * B)(*[int(v) for v in attn_q])
+            ar = torch.zeros(B, S, device=self.device, dtype=torch.float32)
+        self._check(self.lib.anyref_llm_forward(self.h, self._stream(), _ptr(x), ln, B, S, _ptr(hidden), _ptr(logits),
+                                                aq, _ptr(ar)), "llm_forward")
+        return dict(hidden=hidden, logits=logits, attn_row=ar)
+
+    # ---- the reference surface -------------------------------------------------------------
+    @torch.no_grad()
+    def generate(self, clip_images, input_ids, sam_images, sam_resized_sizes, height, width, audios=None,
+                 ref_images=None, output_hidden_states=True, return_dict_in_generate=True, max_new_tokens=128,
+                 attention_masks=None, _return_extras: bool = False):
+        """`AnyRefForCausalLM.generate` (model/anyref.py:647-822)."""
+        ids, lens = self._rows(input_ids, attention_masks)
+        B, Lmax = ids.shape
+        if B > self.max_batch:
+            raise ValueError(f"batch {B} > max_batch {self.max_batch} the handle was created for")
+        clip = clip_images.to(self.device, torch.float32).contiguous()
+        sam = sam_images.to(self.device, torch.float32).contiguous()
+        extra, slots, n_extra = self._extra(ids, lens, audios, self._ref_features(ref_images))
+        height = [int(h) for h in height]
+        width = [int(w) for w in width]
+        rs = torch.tensor([[int(a), int(b)] for a, b in sam_resized_sizes], dtype=torch.int32).contiguous()
+        os_ = torch.tensor([[h, w] for h, w in zip(height, width)], dtype=torch.int32).contiguous()
+        Lout = Lmax + max_new_tokens
+        out_ids = torch.zeros(B, Lout, dtype=torch.long)
+        out_lens = torch.zeros(B, dtype=torch.int32)
+        out_nseg = torch.zeros(B, dtype=torch.int32)
+        offs = torch.zeros(B, dtype=torch.long)
+        cap = sum(self.max_seg * h * w for h, w in zip(height, width))
+        out_masks = torch.empty(cap, device=self.device, dtype=torch.float32)
+        L = 4 * self.cfg.sam.grid
+        out_low = torch.zeros(B, self.max_seg, L, L, device=self.device, dtype=torch.float32)
+        hid = None
+        if _return_extras:
+            hid = torch.empty(B, self.cfg.llm.max_seq, self.cfg.llm.dim, device=self.device, dtype=torch.float32)
+        eos = self.config.eos_token_id if self.config.eos_token_id is not None else -1
+        self._check(self.lib.anyref_generate(
+            self.h, self._stream(), _ptr(clip), _ptr(sam), _ptr(ids), _ptr(lens), B, Lmax, _ptr(extra),
+            _ptr(slots), n_extra, _ptr(rs), _ptr(os_), int(max_new_tokens), int(eos), _ptr(out_ids), _ptr(out_lens),
+            _ptr(out_nseg), _ptr(out_masks), cap, _ptr(offs), _ptr(out_low), _ptr(hid)), "generate")
+        # HF pads finished rows with pad_token_id
+        full = torch.full((B, int(out_lens.max())), int(self.config.pad_token_id or 0), dtype=torch.long)
+        for b in range(B):
+            full[b, : out_lens[b]] = out_ids[b, : out_lens[b]]
+        output_ids = full.to(self.device)
+        if int(out_nseg.sum()) == 0:                      # anyref.py:729-730
+            res = (output_ids, None, (None, None, None))
+        else:
+            pred_masks = []
+            for b in range(B):
+                n, h, w = int(out_nseg[b]), height[b], width[b]
+                o = int(offs[b])
+                pred_masks.append(out_masks[o: o + n * h * w].view(n, h, w))
+            res = (output_ids, pred_masks, (None, None, None))
+        if _return_extras:
+            return res, dict(out_lens=out_lens, nseg=out_nseg, low_res=out_low, hidden=hid)
+        return res
+
+    def forward(self, **kwargs):
+        """`AnyRefForCausalLM.forward` (anyref.py:233-237): dispatch as the reference does."""
+        if "past_key_values" in kwargs:
+            raise NotImplementedError("plain LM forward with past_key_values is handled inside the HIP decode loop")
+        return self.model_forward_new(**kwargs)
+
+    __call__ = forward
+
+    @torch.no_grad()
+    def model_forward_new(self, clip_images, sam_images, input_ids, labels, attention_masks, sam_resized_sizes,
+                          gt_masks, height, width, audios=None, ref_images=None, _return_extras: bool = False,
+                          **kwargs):
+        """Teacher-forced `model_forward_new` (anyref.py:239-466), inference arithmetic on the GPU,
+        losses (`anyref.py:19-68,432-450`) evaluated with torch on the returned logits."""
+        ids, lens = self._rows(input_ids, attention_masks)
+        B, Lmax = ids.shape
+        lab_rows, _ = self._rows(labels, attention_masks)
+        clip = clip_images.to(self.device, torch.float32).contiguous()
+        sam = sam_images.to(self.device, torch.float32).contiguous()
+        extra, slots, n_extra = self._extra(ids, lens, audios, self._ref_features(ref_images))
+        height = [int(h) for h in height]
+        width = [int(w) for w in width]
+        rs = torch.tensor([[int(a), int(b)] for a, b in sam_resized_sizes], dtype=torch.int32).contiguous()
+        os_ = torch.tensor([[h, w] for h, w in zip(height, width)], dtype=torch.int32).contiguous()
+        out_nseg = torch.zeros(B, dtype=torch.int32)
+        offs = torch.zeros(B, dtype=torch.long)
+        cap = sum(self.max_seg * h * w for h, w in zip(height, width))
+        out_masks = torch.empty(cap, device=self.device, dtype=torch.float32)
+        reph = torch.zeros(B, dtype=torch.int32)
+        for b in range(B):
+            pos = (lab_rows[b, : lens[b]] > 0).nonzero().flatten()
+            reph[b] = int(pos[0]) if len(pos) else 0
+        has_img = [(ids[b, : lens[b]] == IMAGE_TOKEN_INDEX).any().item() for b in range(B)]
+        Sp = max(int(lens[b]) + (self.n_img - 1 if has_img[b] else 0) for b in range(B))
+        logits = torch.empty(B, Sp, self.cfg.llm.vocab, device=self.device, dtype=torch.float32)
+        hid = torch.empty(B, self.cfg.llm.max_seq, self.cfg.llm.dim, device=self.device,
+                          dtype=torch.float32) if _return_extras else None
+        self._check(self.lib.anyref_forward_teacher(
+            self.h, self._stream(), _ptr(clip), _ptr(sam), _ptr(ids), _ptr(lens), B, Lmax, _ptr(extra), _ptr(slots),
+            n_extra, _ptr(reph), _ptr(rs), _ptr(os_), _ptr(out_nseg), _ptr(out_masks), cap, _ptr(offs), None,
+            _ptr(hid), _ptr(logits)), "forward_teacher")
+        # LM loss (HF shift-by-one CE; the image span carries IGNORE labels)
+        num, den = torch.zeros((), device=self.device), 0
+        for b in range(B):
+            lab = lab_rows[b, : lens[b]]
+            if has_img[b]:
+                ip = int((ids[b, : lens[b]] == IMAGE_TOKEN_INDEX).nonzero()[0])
+                lab = torch.cat([lab[:ip], torch.full((self.n_img,), -100, dtype=torch.long), lab[ip + 1:]])
+            lab = lab.to(self.device)
+            valid = lab[1:] != -100
+            if valid.any():
+                lg = logits[b, : lab.shape[0] - 1][valid]
+                num = num + F.cross_entropy(lg, lab[1:][valid], reduction="sum")
+                den += int(valid.sum())
+        lm_loss = num / max(den, 1)
+        if int(out_nseg.sum()) == 0:                      # anyref.py:356-365
+            return {"loss": lm_loss, "lm_loss": lm_loss}
+        pred_masks = []
+        for b in range(B):
+            n, h, w = int(out_nseg[b]), height[b], width[b]
+            o = int(offs[b])
+            pred_masks.append(out_masks[o: o + n * h * w].view(n, h, w))
+        out = {"lm_loss": lm_loss}
+        if gt_masks is not None:
+            ce = dice = torch.zeros((), device=self.device)
+            nm = 0
+            for b in range(B):
+                pm, gt = pred_masks[b], gt_masks[b].to(pred_masks[b])
+                if pm.shape[-2:] != gt.shape[-2:]:
+                    pm = F.interpolate(pm[None], size=gt.shape[-2:], mode="bilinear", align_corners=False)[0]
+                ce = ce + sigmoid_ce_loss(pm, gt, gt.shape[0]) * gt.shape[0]
+                dice = dice + dice_loss(pm, gt, gt.shape[0]) * gt.shape[0]
+                nm += gt.shape[0]
+            ce = self.bce_loss_weight * ce / (nm + 1e-8)
+            dice = self.dice_loss_weight * dice / (nm + 1e-8)
+            out.update({"loss": lm_loss + ce + dice, "ce_loss": ce, "dice_loss": dice, "mask_loss": ce + dice})
+        if _return_extras:
+            out.update(pred_masks=pred_masks, hidden=hid, logits=logits)
+        return out
+
+
+def dice_loss(inputs, targets, num_masks, scale=1000, eps=1e-6):
+    """`dice_loss` (model/anyref.py:19-44)."""
+    inputs = inputs.sigmoid().flatten(1, 2)
+    targets = targets.flatten(1, 2)
+    numerator = 2 * (inputs / scale * targets).sum(-1)
+    denominator = (inputs / scale).sum(-1) + (targets / scale).sum(-1)
+    loss = 1 - (numerator + eps) / (denominator + eps)
+    return loss.sum() / (num_masks + 1e-8)
+
+
+def sigmoid_ce_loss(inputs, targets, num_masks):
+    """`sigmoid_ce_loss` (model/anyref.py:47-68)."""
+    loss = F.binary_cross_entropy_with_logits(inputs, targets, reduction="none")
+    return loss.flatten(1, 2).mean(1).sum() / (num_masks + 1e-8)

@@ -1,0 +1,159 @@
+/*
+ * anyref_hip.h — C-ABI of the MI355X-native AnyRef inference backend (libanyref_hip.so).
+ *
+ * The reference (jwh97nn/AnyRef) is pure Python and has NO FFI / plugin layer
+ * (SURVEY.md §8b); its boundary for this path is the Python surface of
+ * `AnyRefForCausalLM` (model/anyref.py:182-237, :647-822) plus the state_dict
+ * key names.  This library sits one level below a Python class that reproduces
+ * that surface (anyref_amd/model.py); every entry point cites the reference
+ * interface whose arithmetic it replaces.
+ *
+ * Conventions
+ *   - plain pointers + sizes only; no torch / STL types cross the boundary
+ *   - every `dev` pointer is HBM memory on the handle's device, owned by the caller
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it
+ *   - return 0 on success, non-zero on error; text via anyref_last_error()
+ *   - one handle per GPU per process; calls on one handle are serialised by the caller
+ */
+#ifndef ANYREF_HIP_H
+#define ANYREF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ANYREF_ABI_VERSION 1
+
+/* dtype codes for anyref_set_weight */
+#define ANYREF_F32 0
+#define ANYREF_BF16 1
+#define ANYREF_F16 2
+
+/* compute modes */
+#define ANYREF_MODE_PARITY 0 /* fp32 activations + fp32-input MFMA (exact fp32 accumulate) */
+#define ANYREF_MODE_PERF 1   /* bf16 weights/activations on bf16 MFMA, fp32 accumulate + fp32 residual stream */
+
+typedef struct anyref_config {
+  int32_t abi_version; /* = ANYREF_ABI_VERSION */
+  int32_t mode;        /* ANYREF_MODE_* */
+  /* CLIP vision tower (HF CLIPVisionModel under the absent model/llava; anyref.py:190-192) */
+  int32_t clip_image, clip_patch, clip_dim, clip_heads, clip_layers_run, clip_mlp;
+  float clip_eps;
+  /* LLaMA decoder (HF LlamaModel; anyref.py:211-215) */
+  int32_t llm_vocab, llm_dim, llm_heads, llm_layers, llm_mlp, llm_max_seq;
+  float llm_rms_eps, llm_rope_theta;
+  /* SAM (build_sam.py:48-108) */
+  int32_t sam_img, sam_patch, sam_dim, sam_depth, sam_heads, sam_mlp_ratio, sam_window;
+  int32_t sam_n_global;
+  int32_t sam_global_idx[8];
+  int32_t sam_out_chans, dec_heads, dec_mlp, dec_depth, num_mask_tokens;
+  /* glue (anyref.py:116-127,161,197-209) */
+  int32_t out_dim, audio_dim;
+  int32_t seg_lo, seg_hi; /* inclusive [SEG] id range */
+  float rephrase_weight;
+  int32_t max_batch; /* images per call on this GPU */
+  int32_t max_seg;   /* [SEG] tokens per image the workspaces are sized for */
+} anyref_config;
+
+typedef struct anyref_handle anyref_handle;
+
+/* Build an empty model on HIP device `device`. */
+int anyref_create(const anyref_config* cfg, int device, anyref_handle** out);
+void anyref_destroy(anyref_handle* h);
+const char* anyref_last_error(anyref_handle* h); /* h may be NULL: error of the last failed create */
+
+/*
+ * Hand over one tensor under its reference state_dict name (SURVEY.md §8b "Weight names":
+ * `model.visual_model.*`, `model.text_hidden_fcs.0.{0,2}.*`, `model.audio_projector.*`,
+ * `model.layers.*`, `lm_head.weight`, `model.vision_tower.vision_tower.vision_model.*`,
+ * `model.mm_projector.*`).  Replaces `load_state_dict` (build_sam.py:104-107,
+ * eval_referseg.py:70-88).  `ptr` may be host or device memory (`is_device`); the
+ * library keeps its own copy.  Unknown names are ignored and counted.
+ */
+int anyref_set_weight(anyref_handle* h, const char* name, const void* ptr, int is_device,
+                      int dtype, const int64_t* shape, int ndim);
+/* Pack / fuse / convert the weights for the chosen mode; reports missing tensors. */
+int anyref_finalize(anyref_handle* h);
+
+/*
+ * AnyRefForCausalLM.generate (model/anyref.py:647-822).
+ *   clip_images  f32 [B,3,clip_image,clip_image]  dev
+ *   sam_images   f32 [B,3,sam_img,sam_img]        dev
+ *   input_ids    i64 [B,Lmax] host; negative ids are placeholders (-200 image: expands 1->n_patches)
+ *   lens         i32 [B] host: true prompt length of each row (no padding semantics: every row
+ *                is decoded exactly as the reference decodes a batch of one)
+ *   extra_embeds f32 [n_extra, llm_dim] dev or NULL: rows that REPLACE token embeddings 1:1
+ *                (projected audio / reference-image features, anyref.py:663-702)
+ *   extra_slots  i32 [n_extra,2] host: (batch row, position in input_ids) of each extra row
+ *   resized_hw / orig_hw  i32 [B,2] host: sam_resized_sizes and (height,width) (anyref.py:814-818)
+ *   max_new_tokens, eos_token_id (<0 disables EOS)
+ * outputs
+ *   out_ids   i64 [B, Lmax+max_new_tokens] host, out_lens i32 [B] host
+ *   out_nseg  i32 [B] host: number of [SEG] tokens found per image (anyref.py:723-726)
+ *   out_masks f32 dev: mask logits; image b, seg j at offset mask_offsets[b] + j*H_b*W_b,
+ *             capacity `out_masks_cap` floats (error if exceeded); mask_offsets i64 [B] host
+ *   out_low   f32 dev or NULL: low-res logits [B, max_seg, 4g, 4g] (what a DP driver all-gathers)
+ *   out_hidden f32 dev or NULL: [B, llm_max_seq, llm_dim] last-layer post-norm states
+ *             (`outputs.hidden_states[-1]`, anyref.py:718)
+ */
+int anyref_generate(anyref_handle* h, void* stream, const float* clip_images, const float* sam_images,
+                    const int64_t* input_ids, const int32_t* lens, int B, int Lmax,
+                    const float* extra_embeds, const int32_t* extra_slots, int n_extra,
+                    const int32_t* resized_hw, const int32_t* orig_hw, int max_new_tokens,
+                    int eos_token_id, int64_t* out_ids, int32_t* out_lens, int32_t* out_nseg,
+                    float* out_masks, int64_t out_masks_cap, int64_t* mask_offsets, float* out_low,
+                    float* out_hidden);
+
+/*
+ * Teacher-forced path of `model_forward_new` (model/anyref.py:239-430): same arithmetic with the
+ * ids given, no decode loop.  [SEG] positions are searched in input_ids itself and the hidden
+ * state at pos-1+255 is used (anyref.py:273-282).  `out_logits` f32 dev or NULL:
+ * [B, Smax, vocab] LM logits for the caller's CE loss (losses stay in Python, anyref.py:19-68).
+ */
+int anyref_forward_teacher(anyref_handle* h, void* stream, const float* clip_images,
+                           const float* sam_images, const int64_t* input_ids, const int32_t* lens,
+                           int B, int Lmax, const float* extra_embeds, const int32_t* extra_slots,
+                           int n_extra, const int32_t* rephrase_start, const int32_t* resized_hw,
+                           const int32_t* orig_hw, int32_t* out_nseg, float* out_masks,
+                           int64_t out_masks_cap, int64_t* mask_offsets, float* out_low,
+                           float* out_hidden, float* out_logits);
+
+/* ---- stage entry points (each is one reference function; used by the parity tests) ---- */
+
+/* LLaVA encode_images = CLIP hidden_states[-2][:,1:] -> mm_projector (anyref.py:334).
+ * out f32 [B, n_patches, llm_dim] dev; clip_feat f32 [B,n_patches,clip_dim] dev or NULL. */
+int anyref_encode_images(anyref_handle* h, void* stream, const float* clip_images, int B, float* out,
+                         float* clip_feat);
+/* ImageEncoderViT.forward (image_encoder.py:110-125). out f32 [B, g*g, out_chans] dev (NHWC tokens;
+ * the reference's NCHW [B,256,g,g] is this transposed). */
+int anyref_sam_encode(anyref_handle* h, void* stream, const float* sam_images, int B, float* out);
+/* prompt_encoder(text) + mask_decoder.predict_masks + postprocess_masks for one image
+ * (anyref.py:797-819).  image_emb f32 [g*g, out_chans] dev, pred_emb f32 [n,out_dim] dev.
+ * masks4 f32 [n,4,4g,4g] dev or NULL, iou f32 [n,4] dev or NULL,
+ * out_masks f32 [n,H,W] dev or NULL (needs resized_hw, orig_hw i32[2] host). */
+int anyref_mask_decode(anyref_handle* h, void* stream, const float* image_emb, const float* pred_emb,
+                       int n, float* masks4, float* iou, const int32_t* resized_hw,
+                       const int32_t* orig_hw, float* out_masks);
+/* LLaMA stack on given input embeddings (HF LlamaModel; call sites anyref.py:341-354).
+ * embeds f32 [B,S,dim] dev, lens i32[B] host.  hidden f32 [B,S,dim] (post final norm),
+ * logits f32 [B,S,vocab] or NULL, attn_row f32 [B,S] or NULL = head-mean last-layer attention of
+ * query `attn_q[b]` (i32[B] host) over all keys (anyref.py:748-749). */
+int anyref_llm_forward(anyref_handle* h, void* stream, const float* embeds, const int32_t* lens, int B,
+                       int S, float* hidden, float* logits, const int32_t* attn_q, float* attn_row);
+
+/* audio_projector = Linear(audio_dim, llm_dim) on ImageBind audio embeddings (anyref.py:161,673).
+ * audio_emb f32 [n, audio_dim] dev (the ImageBind trunk itself stays a PyTorch-ROCm step) ->
+ * out f32 [n, llm_dim] dev, ready to be passed as `extra_embeds`. */
+int anyref_project_audio(anyref_handle* h, void* stream, const float* audio_emb, int n, float* out);
+
+/* Bytes of HBM the handle holds (weights + workspaces), for sizing reports. */
+int64_t anyref_device_bytes(anyref_handle* h);
+/* Name of the compute mode's arithmetic ("f32" / "bf16"). */
+const char* anyref_mode_name(anyref_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ANYREF_HIP_H */

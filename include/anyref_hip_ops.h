@@ -1,0 +1,39 @@
+/*
+ * anyref_hip_ops.h — kernel-level entry points of libanyref_hip.so used by the parity tests
+ * (tests/test_gpu_ops.py) to check every hand-written kernel against the oracle / torch fp32 in
+ * isolation.  Not part of the drop-in boundary (that is anyref_hip.h).
+ * `t` selects the storage type: 0 = f32 (MFMA 16x16x4 f32), 1 = bf16 (MFMA 16x16x32 bf16).
+ * All pointers are device pointers; `stream` is a hipStream_t.
+ */
+#ifndef ANYREF_HIP_OPS_H
+#define ANYREF_HIP_OPS_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* C[row_map[m]] = act(A W^T + bias) + resid; A,W in type t; C f32 if c_f32 else t */
+int anyref_op_gemm(int t, void* stream, const void* A, const void* W, const float* bias, void* C,
+                   const float* resid, const int32_t* row_map, int M, int N, int K, int act, int c_f32);
+/* y = act(rmsnorm?(x) W^T) [* (x W2^T)] + resid;  x,y f32; W in type t */
+int anyref_op_gemv(int t, void* stream, const float* x, const float* gain, float eps, const void* W,
+                   const void* W2, const float* bias, float* y, const float* resid, int B, int N, int K, int act);
+/* LayerNorm (rms=0) / RMSNorm (rms=1); x f32, y f32 */
+int anyref_op_norm(int t, void* stream, const float* x, const float* gain, const float* bias, float* y, int M,
+                   int D, float eps, int rms);
+/* q,k,v,o [B,S,H,hd] contiguous in type t; rel_h/rel_w f32 [B,H,Sq,kh|kw] or NULL */
+int anyref_op_attention(int t, void* stream, const void* q, const void* k, const void* v, void* o, int B, int H,
+                        int Sq, int Sk, int hd, float scale, int causal, const int32_t* kv_len,
+                        const float* rel_h, const float* rel_w, int kh, int kw);
+/* SAM decomposed rel-pos tables from q [B,S=size*size,H,hd] (type t) */
+int anyref_op_rel_pos(int t, void* stream, const void* q, const float* tab_h, const float* tab_w, int B, int H,
+                      int size, int hd, float* rel_h, float* rel_w);
+/* Sam.postprocess_masks on low [n,lh,lw] f32 */
+int anyref_op_postprocess(void* stream, const float* low, int n, int lh, int lw, int S, int rh, int rw, int H,
+                          int W, float* out);
+const char* anyref_op_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

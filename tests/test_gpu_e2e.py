@@ -1,0 +1,152 @@
+"""End-to-end parity of `generate` / `forward` through the Python mirror + C-ABI against the CPU
+oracle on the tiny plumbing config (BASELINE.json configs[0]).
+
+Bar (north_star): identical greedy token ids and mask logits within 1e-3 (parity mode).  The bf16
+perf mode is measured against the same oracle and must stay within a stated looser bound; its
+measured error is what bench.py reports."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from anyref_amd.config import config_tiny, IMAGE_TOKEN_INDEX, AUDIO_REF_INDEX  # noqa: E402
+from anyref_amd.synth import synth_state_dict  # noqa: E402
+from oracle import anyref_oracle as O  # noqa: E402
+
+MASK_TOL = 1e-3          # north_star bound, parity mode
+PERF_MASK_TOL = 5e-2     # bf16 operands; logits of the tiny random model are O(1)
+
+
+def make_inputs(cfg, B, seed, L=16, audio=False):
+    g = torch.Generator().manual_seed(seed)
+    S = cfg.sam.img_size
+    clip = torch.randn(B, 3, cfg.clip.image_size, cfg.clip.image_size, generator=g)
+    sam = torch.randn(B, 3, S, S, generator=g)
+    ids = []
+    for b in range(B):
+        n = L - 3 * b
+        body = torch.randint(3, cfg.llm.vocab - 10, (n - 2,), generator=g)
+        row = torch.cat([torch.tensor([1, IMAGE_TOKEN_INDEX]), body])
+        if audio:
+            row = torch.cat([row[:5], torch.full((3,), AUDIO_REF_INDEX), row[5:]])
+        ids.append(row)
+    return clip, sam, ids
+
+
+def pad(ids, pad_id=0):
+    L = max(len(r) for r in ids)
+    out = torch.full((len(ids), L), pad_id, dtype=torch.long)
+    mask = torch.zeros(len(ids), L, dtype=torch.bool)
+    for b, r in enumerate(ids):
+        out[b, : len(r)] = r
+        mask[b, : len(r)] = True
+    return out, mask
+
+
+def rig_seg(cfg, sd, clip, sam, ids, sizes, hw, **kw):
+    """make the random model emit a [SEG] by naming the id it emits at step 3."""
+    cfg.seg_token_idx = cfg.llm.vocab - 1
+    with torch.no_grad():
+        r0 = O.anyref_generate(sd, cfg, clip[:1], ids[:1], sam[:1], sizes[:1], hw[0][:1], hw[1][:1], max_new_tokens=4,
+                               eos=False, **kw)
+    cfg.seg_token_idx = int(r0["output_ids"][0][-2])
+
+
+@pytest.mark.parametrize("mode", ["parity", "perf"])
+@pytest.mark.parametrize("window,sam_dim,sam_heads", [(14, 192, 3), (4, 160, 2)])
+def test_generate_matches_oracle(mode, window, sam_dim, sam_heads):
+    from anyref_amd.model import AnyRefForCausalLM
+    cfg = config_tiny(window=window, sam_dim=sam_dim, sam_heads=sam_heads)
+    sd = synth_state_dict(cfg, seed=3, scale=0.05)
+    clip, sam, ids = make_inputs(cfg, 1, seed=4)
+    sizes, H, W = [(224, 180)], [300], [241]
+    rig_seg(cfg, sd, clip, sam, ids, sizes, (H, W))
+    with torch.no_grad():
+        ref = O.anyref_generate(sd, cfg, clip, ids, sam, sizes, H, W, max_new_tokens=6, eos=False)
+    assert ref["pred_masks"] is not None
+    m = AnyRefForCausalLM.from_state_dict(cfg, {k: v.cuda() for k, v in sd.items()}, mode=mode, max_batch=1, max_seg=4)
+    m.config.eos_token_id = None
+    (out_ids, masks, rest), ex = m.generate(clip, ids[0][None], sam, sizes, H, W, max_new_tokens=6, _return_extras=True)
+    assert rest == (None, None, None)
+    if mode == "parity":
+        assert out_ids[0].cpu().tolist() == ref["output_ids"][0].tolist(), "greedy ids differ"
+    n = ref["hidden"][0].shape[0]
+    herr = (ex["hidden"][0, :n].cpu() - ref["hidden"][0]).abs().max().item()
+    assert herr < (2e-4 if mode == "parity" else 0.15), f"hidden err {herr}"
+    if out_ids[0].cpu().tolist() == ref["output_ids"][0].tolist():
+        assert masks[0].shape == ref["pred_masks"][0].shape
+        err = (masks[0].cpu() - ref["pred_masks"][0]).abs().max().item()
+        print(f"[{mode}] mask-logit max-abs-err {err:.3e} (range ±{ref['pred_masks'][0].abs().max():.2f})")
+        assert err <= (MASK_TOL if mode == "parity" else PERF_MASK_TOL)
+
+
+def test_generate_batch_audio_eos_and_noseg():
+    """Ragged batch of 2 with audio placeholders: every row equals the oracle's batch-of-one run;
+    EOS stops a row; no [SEG] -> (ids, None, (None,)*3)  (anyref.py:729-730)."""
+    from anyref_amd.model import AnyRefForCausalLM
+    cfg = config_tiny()
+    sd = synth_state_dict(cfg, seed=5, scale=0.05)
+    clip, sam, ids = make_inputs(cfg, 2, seed=6, audio=True)
+    g = torch.Generator().manual_seed(9)
+    aud = [torch.randn(3, cfg.audio_dim, generator=g), torch.randn(3, cfg.audio_dim, generator=g)]
+    sizes, H, W = [(224, 224), (200, 224)], [224, 120], [224, 333]
+    rig_seg(cfg, sd, clip, sam, ids, sizes, (H, W), audio_embeds=aud)
+    with torch.no_grad():
+        ref = O.anyref_generate(sd, cfg, clip, ids, sam, sizes, H, W, audio_embeds=aud, max_new_tokens=5, eos=False)
+    m = AnyRefForCausalLM.from_state_dict(cfg, {k: v.cuda() for k, v in sd.items()}, mode="parity", max_batch=2, max_seg=4)
+    m.config.eos_token_id = None
+    padded, mask = pad(ids)
+    out_ids, masks, _ = m.generate(clip, padded, sam, sizes, H, W, audios=aud, max_new_tokens=5, attention_masks=mask)
+    for b in range(2):
+        got = out_ids[b].cpu()
+        want = ref["output_ids"][b]
+        assert got[: len(want)].tolist() == want.tolist(), f"row {b} ids differ"
+        if ref["pred_masks"][b].shape[0]:
+            err = (masks[b].cpu() - ref["pred_masks"][b]).abs().max().item()
+            assert err <= MASK_TOL, f"row {b} mask err {err}"
+        else:
+            assert masks[b].shape[0] == 0
+    # EOS: name the 2nd generated token of row 0 as EOS -> generation stops right there
+    eos = int(ref["output_ids"][0][len(ids[0]) + 1])
+    m.config.eos_token_id = eos
+    o2, _, _ = m.generate(clip[:1], ids[0][None], sam[:1], sizes[:1], H[:1], W[:1], audios=aud[:1], max_new_tokens=5)
+    assert o2.shape[1] == len(ids[0]) + 2 and int(o2[0, -1]) == eos
+    # no [SEG] anywhere
+    m2cfg = config_tiny()
+    m2cfg.seg_token_idx = cfg.llm.vocab + 5
+    m2 = AnyRefForCausalLM.from_state_dict(m2cfg, {k: v.cuda() for k, v in sd.items()}, mode="parity")
+    m2.config.eos_token_id = None
+    o3, masks3, rest = m2.generate(clip[:1], ids[0][None], sam[:1], sizes[:1], H[:1], W[:1], audios=aud[:1], max_new_tokens=3)
+    assert masks3 is None and rest == (None, None, None)
+
+
+def test_rephrase_and_teacher_forward():
+    """rephrase branch (anyref.py:735-755) in generate, and the teacher-forced forward with losses."""
+    from anyref_amd.model import AnyRefForCausalLM
+    cfg = config_tiny()
+    cfg.rephrase_weight = 0.5
+    sd = synth_state_dict(cfg, seed=7, scale=0.05)
+    clip, sam, ids = make_inputs(cfg, 1, seed=8)
+    sizes, H, W = [(224, 224)], [224], [224]
+    rig_seg(cfg, sd, clip, sam, ids, sizes, (H, W))
+    with torch.no_grad():
+        ref = O.anyref_generate(sd, cfg, clip, ids, sam, sizes, H, W, max_new_tokens=6, eos=False)
+    m = AnyRefForCausalLM.from_state_dict(cfg, {k: v.cuda() for k, v in sd.items()}, mode="parity", max_seg=4)
+    m.config.eos_token_id = None
+    out_ids, masks, _ = m.generate(clip, ids[0][None], sam, sizes, H, W, max_new_tokens=6)
+    assert out_ids[0].cpu().tolist() == ref["output_ids"][0].tolist()
+    err = (masks[0].cpu() - ref["pred_masks"][0]).abs().max().item()
+    assert err <= MASK_TOL, f"rephrase mask err {err}"
+    # teacher-forced forward on the generated sequence (labels: answer part only)
+    full = ref["output_ids"][0]
+    labels = full.clone()
+    labels[: len(ids[0])] = -100
+    gt = [(torch.rand(ref["pred_masks"][0].shape[0], 224, 224) > 0.5).float()]
+    with torch.no_grad():
+        fr = O.anyref_forward(sd, cfg, clip, sam, [full], [labels], sizes, gt, H, W)
+    out = m.model_forward_new(clip, sam, full[None], labels[None], None, sizes, gt, H, W, _return_extras=True)
+    assert abs(float(out["lm_loss"]) - float(fr["lm_loss"])) < 1e-3
+    perr = (out["pred_masks"][0].cpu() - fr["pred_masks"][0]).abs().max().item()
+    assert perr <= MASK_TOL, f"forward mask err {perr}"
+    for k in ("ce_loss", "dice_loss", "mask_loss", "loss"):
+        assert abs(float(out[k]) - float(fr[k])) < 2e-3, k

@@ -1,0 +1,205 @@
+"""Kernel-level parity: every hand-written HIP kernel against a plain torch fp32 reference of
+the same op, through the C-ABI test entry points (include/anyref_hip_ops.h).
+
+t=0 is the parity arithmetic (f32 MFMA, must agree to ~1e-5 relative), t=1 the perf arithmetic
+(bf16 MFMA operands, fp32 accumulate; tolerance = bf16 rounding of the operands).
+"""
+import ctypes as C
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL = {0: 2e-5, 1: 2e-2}
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from anyref_amd import _lib
+    return _lib.load()
+
+
+def dev(t, ty):
+    t = t.cuda()
+    return t.to(torch.bfloat16).contiguous() if ty == 1 else t.float().contiguous()
+
+
+def rnd(t, ty):
+    """what the kernel sees after storage rounding"""
+    return t.to(torch.bfloat16).float() if ty == 1 else t
+
+
+def P(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def check(lib, rc):
+    assert rc == 0, lib.anyref_op_last_error().decode()
+    torch.cuda.synchronize()
+
+
+def close(got, ref, tol):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    err = (got - ref).abs().max().item()
+    scale = max(1.0, ref.abs().max().item())
+    assert math.isfinite(err) and err <= tol * scale, f"max abs err {err:.3e} vs scale {scale:.3e} (tol {tol})"
+
+
+@pytest.mark.parametrize("ty", [0, 1])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (257, 192, 192), (320, 384, 1032), (6, 256, 256), (1000, 64, 72),
+                                   (70, 130, 24)])
+@pytest.mark.parametrize("act", [0, 1, 2, 3, 4])
+def test_gemm(lib, ty, M, N, K, act):
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K + act)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) * 0.1
+    bias = torch.randn(N, generator=g)
+    resid = torch.randn(M, N, generator=g)
+    z = rnd(A, ty) @ rnd(W, ty).t() + bias
+    ref = [z, torch.relu(z), torch.nn.functional.gelu(z), z * torch.sigmoid(1.702 * z), torch.nn.functional.silu(z)][act]
+    ref = ref + resid
+    Ad, Wd, bd, rd = dev(A, ty), dev(W, ty), bias.cuda(), resid.cuda()
+    out = torch.empty(M, N, device="cuda")
+    check(lib, lib.anyref_op_gemm(ty, None, P(Ad), P(Wd), P(bd), P(out), P(rd), None, M, N, K, act, 1))
+    close(out, ref, TOL[ty] * 4)
+
+
+@pytest.mark.parametrize("ty", [0, 1])
+def test_gemm_row_map_and_typed_out(lib, ty):
+    M, N, K = 200, 96, 64
+    g = torch.Generator().manual_seed(5)
+    A, W = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.1
+    perm = torch.randperm(M, generator=g).to(torch.int32)
+    perm[::7] = -1                                  # dropped rows (window padding)
+    ref = torch.zeros(M, N)
+    z = rnd(A, ty) @ rnd(W, ty).t()
+    for m in range(M):
+        if perm[m] >= 0:
+            ref[perm[m]] = z[m]
+    out = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16 if ty == 1 else torch.float32)
+    check(lib, lib.anyref_op_gemm(ty, None, P(dev(A, ty)), P(dev(W, ty)), None, P(out), None, P(perm.cuda()), M, N,
+                                  K, 0, 0))
+    close(out, ref, 1e-2 if ty else 1e-4)
+
+
+@pytest.mark.parametrize("ty", [0, 1])
+@pytest.mark.parametrize("B,N,K,dual,norm", [(1, 512, 256, 0, 1), (2, 1000, 688, 1, 1), (4, 300, 1024, 0, 0),
+                                             (3, 64, 4096, 1, 0), (1, 33, 11008, 0, 1)])
+def test_gemv(lib, ty, B, N, K, dual, norm):
+    g = torch.Generator().manual_seed(B + N + K)
+    x = torch.randn(B, K, generator=g)
+    W, W2 = torch.randn(N, K, generator=g) * 0.05, torch.randn(N, K, generator=g) * 0.05
+    gain = 1 + 0.1 * torch.randn(K, generator=g)
+    resid = torch.randn(B, N, generator=g)
+    xn = x
+    if norm:
+        xn = x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-6) * gain
+    xn = rnd(xn, ty)
+    z = xn @ rnd(W, ty).t()
+    if dual:
+        z = torch.nn.functional.silu(z) * (xn @ rnd(W2, ty).t())
+    ref = z + resid
+    y = torch.empty(B, N, device="cuda")
+    check(lib, lib.anyref_op_gemv(ty, None, P(x.cuda()), P(gain.cuda()) if norm else None, 1e-6, P(dev(W, ty)),
+                                  P(dev(W2, ty)) if dual else None, None, P(y), P(resid.cuda()), B, N, K, 0))
+    close(y, ref, TOL[ty] * 4)
+
+
+@pytest.mark.parametrize("rms", [0, 1])
+@pytest.mark.parametrize("M,D", [(5, 64), (300, 192), (257, 1024), (33, 1280), (9, 4096), (3, 5120)])
+def test_norm(lib, rms, M, D):
+    g = torch.Generator().manual_seed(M + D)
+    x = torch.randn(M, D, generator=g) * 3 + 1
+    gain, bias = torch.randn(D, generator=g), torch.randn(D, generator=g)
+    if rms:
+        ref = x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-6) * gain
+    else:
+        ref = torch.nn.functional.layer_norm(x, (D,), gain, bias, 1e-6)
+    y = torch.empty(M, D, device="cuda")
+    check(lib, lib.anyref_op_norm(0, None, P(x.cuda()), P(gain.cuda()), None if rms else P(bias.cuda()), P(y), M, D,
+                                  1e-6, rms))
+    close(y, ref, 2e-5)
+
+
+def ref_attention(q, k, v, scale, causal, kv_len, rel_h, rel_w, kw):
+    B, Sq, H, hd = q.shape
+    Sk = k.shape[1]
+    s = torch.einsum("bqhd,bkhd->bhqk", q, k) * scale
+    if rel_h is not None:
+        kh = rel_h.shape[-1]
+        s = (s.view(B, H, Sq, kh, kw) + rel_h[..., :, None] + rel_w[..., None, :]).view(B, H, Sq, Sk)
+    mask = torch.zeros(B, 1, Sq, Sk, dtype=torch.bool)
+    if kv_len is not None:
+        for b in range(B):
+            mask[b, :, :, kv_len[b]:] = True
+    if causal:
+        mask |= torch.ones(Sq, Sk, dtype=torch.bool).triu(1)
+    s = s.masked_fill(mask, float("-inf"))
+    return torch.einsum("bhqk,bkhd->bqhd", torch.softmax(s, -1), v)
+
+
+@pytest.mark.parametrize("ty", [0, 1])
+@pytest.mark.parametrize("B,H,Sq,Sk,hd,causal", [
+    (2, 3, 257, 257, 64, 0),      # CLIP
+    (1, 4, 320, 320, 128, 1),     # LLaMA prefill
+    (2, 2, 1, 200, 128, 0),       # decode step
+    (3, 8, 6, 196, 16, 0),        # mask decoder token -> image
+    (3, 8, 196, 6, 16, 0),        # image -> token
+    (3, 8, 6, 6, 32, 0),          # token self attention
+    (2, 2, 130, 130, 80, 1),      # hd 80, causal, ragged tail tiles
+    (2, 2, 100, 130, 80, 0),      # hd 80, Sq != Sk
+])
+def test_attention(lib, ty, B, H, Sq, Sk, hd, causal):
+    g = torch.Generator().manual_seed(Sq * 3 + Sk + hd)
+    q, k, v = (torch.randn(B, S, H, hd, generator=g) for S in (Sq, Sk, Sk))
+    kv_len = None
+    if B > 1 and Sk > 64 and not causal:
+        kv_len = torch.tensor([Sk - 7 * b for b in range(B)], dtype=torch.int32)
+    scale = hd ** -0.5
+    ref = ref_attention(rnd(q, ty), rnd(k, ty), rnd(v, ty), scale, causal, kv_len, None, None, 0)
+    o = torch.empty(B, Sq, H, hd, device="cuda", dtype=torch.bfloat16 if ty else torch.float32)
+    check(lib, lib.anyref_op_attention(ty, None, P(dev(q, ty)), P(dev(k, ty)), P(dev(v, ty)), P(o), B, H, Sq, Sk, hd,
+                                       scale, causal, P(kv_len.cuda()) if kv_len is not None else None, None, None,
+                                       0, 0))
+    close(o, ref, 3e-2 if ty else 3e-5)
+
+
+@pytest.mark.parametrize("ty", [0, 1])
+@pytest.mark.parametrize("B,H,size,hd", [(3, 2, 14, 80), (1, 2, 16, 64), (2, 3, 4, 64)])
+def test_sam_attention_rel_pos(lib, ty, B, H, size, hd):
+    """windowed / global SAM attention incl. the decomposed rel-pos bias (image_encoder.py:231-392)."""
+    g = torch.Generator().manual_seed(size + hd)
+    S = size * size
+    q, k, v = (torch.randn(B, S, H, hd, generator=g) for _ in range(3))
+    th, tw = torch.randn(2 * size - 1, hd, generator=g) * 0.3, torch.randn(2 * size - 1, hd, generator=g) * 0.3
+    idx = torch.arange(size)[:, None] - torch.arange(size)[None, :] + size - 1
+    qr = rnd(q, ty)
+    rq = qr.permute(0, 2, 1, 3).reshape(B, H, size, size, hd)
+    rel_h = torch.einsum("bnhwc,hkc->bnhwk", rq, th[idx]).reshape(B, H, S, size)
+    rel_w = torch.einsum("bnhwc,wkc->bnhwk", rq, tw[idx]).reshape(B, H, S, size)
+    rh = torch.empty(B, H, S, size, device="cuda")
+    rw = torch.empty(B, H, S, size, device="cuda")
+    check(lib, lib.anyref_op_rel_pos(ty, None, P(dev(q, ty)), P(th.cuda()), P(tw.cuda()), B, H, size, hd, P(rh), P(rw)))
+    close(rh, rel_h, 1e-4)
+    close(rw, rel_w, 1e-4)
+    scale = hd ** -0.5
+    ref = ref_attention(qr, rnd(k, ty), rnd(v, ty), scale, False, None, rel_h, rel_w, size)
+    o = torch.empty(B, S, H, hd, device="cuda", dtype=torch.bfloat16 if ty else torch.float32)
+    check(lib, lib.anyref_op_attention(ty, None, P(dev(q, ty)), P(dev(k, ty)), P(dev(v, ty)), P(o), B, H, S, S, hd,
+                                       scale, 0, None, P(rh), P(rw), size, size))
+    close(o, ref, 3e-2 if ty else 5e-5)
+
+
+@pytest.mark.parametrize("n,lh,S,rs,os_", [(2, 56, 224, (224, 224), (224, 224)), (3, 56, 224, (150, 224), (301, 437)),
+                                           (1, 256, 1024, (683, 1024), (427, 640))])
+def test_postprocess(lib, n, lh, S, rs, os_):
+    g = torch.Generator().manual_seed(n + lh)
+    low = torch.randn(n, 1, lh, lh, generator=g)
+    m = torch.nn.functional.interpolate(low, (S, S), mode="bilinear", align_corners=False)[..., : rs[0], : rs[1]]
+    ref = torch.nn.functional.interpolate(m, os_, mode="bilinear", align_corners=False)[:, 0]
+    out = torch.empty(n, os_[0], os_[1], device="cuda")
+    check(lib, lib.anyref_op_postprocess(None, P(low.cuda().contiguous()), n, lh, lh, S, rs[0], rs[1], os_[0], os_[1],
+                                         P(out)))
+    close(out, ref, 2e-5)
