@@ -198,8 +198,9 @@ struct Vec16<bf16> {
   static __device__ inline void unpack(const uint4v& v, float* f) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      f[2 * i] = __builtin_bit_cast(float, v[i] << 16);
-      f[2 * i + 1] = __builtin_bit_cast(float, v[i] & 0xffff0000u);
+      const uint32_t u = v[i];
+      f[2 * i] = __builtin_bit_cast(float, u << 16);
+      f[2 * i + 1] = __builtin_bit_cast(float, u & 0xffff0000u);
     }
   }
 };
@@ -208,7 +209,12 @@ struct Vec16<float> {
   static constexpr int N = 4;
   static __device__ inline void unpack(const uint4v& v, float* f) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) f[i] = __builtin_bit_cast(float, v[i]);
+    for (int i = 0; i < 4; ++i) {
+      // NB: __builtin_bit_cast applied directly to an ext_vector element (v[i]) reads element 0
+      // for every i on hipcc/ROCm 7.2; go through a scalar temporary.
+      const uint32_t u = v[i];
+      f[i] = __builtin_bit_cast(float, u);
+    }
   }
 };
 

@@ -31,13 +31,22 @@ def rnd(t, ty):
     return t.to(torch.bfloat16).float() if ty == 1 else t
 
 
+_KEEP = []
+
+
 def P(t):
-    return None if t is None else C.c_void_p(t.data_ptr())
+    """device pointer of t; t is kept alive until check() has synchronised (a temporary's block
+    would otherwise go back to the caching allocator before the kernel runs)."""
+    if t is None:
+        return None
+    _KEEP.append(t)
+    return C.c_void_p(t.data_ptr())
 
 
 def check(lib, rc):
     assert rc == 0, lib.anyref_op_last_error().decode()
     torch.cuda.synchronize()
+    _KEEP.clear()
 
 
 def close(got, ref, tol):
