@@ -58,6 +58,11 @@ SYMBOLS = {
     "anyref_mask_decode": (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
     "anyref_llm_forward": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
     "anyref_project_audio": (_I, [_P, _P, _P, _I, _P]),
+    "anyref_set_seg_range": (_I, [_P, _I, _I]),
+    "anyref_profile_enable": (_I, [_P, _I]),
+    "anyref_profile_collect": (_I, [_P]),
+    "anyref_profile_read": (_I, [_P, _I, C.c_char_p, _I, C.POINTER(C.c_double), C.POINTER(_L),
+                                C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "anyref_device_bytes": (_L, [_P]),
     "anyref_mode_name": (C.c_char_p, [_P]),
     # kernel-level test entry points (anyref_hip_ops.h)

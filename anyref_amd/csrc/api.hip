@@ -17,6 +17,10 @@ static thread_local std::string g_create_err;
 #define GUARD(h, body)                         \
   if (!(h) || !(h)->m) return 1;               \
   try {                                        \
+    struct ProfInstall {                       \
+      ProfInstall(Profiler* p) { g_prof = p; } \
+      ~ProfInstall() { g_prof = nullptr; }     \
+    } _pi(&(h)->m->prof);                      \
     body;                                      \
     hipError_t _e = hipGetLastError();         \
     if (_e != hipSuccess) {                    \
@@ -107,6 +111,30 @@ int anyref_llm_forward(anyref_handle* h, void* stream, const float* embeds, cons
 
 int anyref_project_audio(anyref_handle* h, void* stream, const float* audio_emb, int n, float* out) {
   GUARD(h, h->m->project_audio((hipStream_t)stream, audio_emb, n, out));
+}
+
+int anyref_set_seg_range(anyref_handle* h, int lo, int hi) { GUARD(h, h->m->set_seg_range(lo, hi)); }
+
+int anyref_profile_enable(anyref_handle* h, int on) {
+  GUARD(h, {
+    h->m->prof.on = on != 0;
+    if (on) h->m->prof.reset();
+  });
+}
+
+int anyref_profile_collect(anyref_handle* h) { GUARD(h, h->m->prof.collect()); }
+
+int anyref_profile_read(anyref_handle* h, int idx, char* name, int cap, double* ms, int64_t* count, double* flops,
+                        double* bytes) {
+  if (!h || !h->m) return -1;
+  auto st = h->m->prof.stats();
+  if (idx < 0 || idx >= (int)st.size()) return -1;
+  snprintf(name, cap, "%s", st[idx].first.c_str());
+  *ms = st[idx].second.ms;
+  *count = st[idx].second.count;
+  *flops = st[idx].second.flops;
+  *bytes = st[idx].second.bytes;
+  return 0;
 }
 
 int64_t anyref_device_bytes(anyref_handle* h) { return h && h->m ? h->m->device_bytes() : 0; }

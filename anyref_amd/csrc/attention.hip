@@ -263,6 +263,10 @@ static void attn_launch(const AttnArgs& a, hipStream_t s) {
     attr = true;
   }
   dim3 grid(cdiv(a.Sq, 64), a.H, a.B);
+  static const std::string tag = std::string(sizeof(T) == 2 ? "attn_bf16_hd" : "attn_f32_hd") + std::to_string(HD);
+  const double flops = 4.0 * a.B * a.H * (double)a.Sq * a.Sk * HD * (a.causal ? 0.5 : 1.0);
+  const double bytes = (double)a.B * a.H * HD * sizeof(T) * (2.0 * a.Sq + 2.0 * a.Sk);
+  ProfScope prof(tag.c_str(), flops, bytes, s);
   hipLaunchKernelGGL((attn_kernel<T, HD>), grid, dim3(256), lds, s, a);
 }
 

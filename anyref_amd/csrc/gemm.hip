@@ -167,6 +167,14 @@ void launch_gemm(const GemmArgs& a, hipStream_t s) {
     if (blocks(bm128 ? 128 : 64, 128) < 256) bn = 64;
   }
   dim3 block(256);
+  const double flops = 2.0 * a.M * a.N * (double)a.K * a.batch;
+  const double bytes = ((double)a.M * a.K + (double)a.N * a.K) * sizeof(T) * a.batch +
+                       (double)a.M * a.N * (a.c_f32 ? 4 : sizeof(T)) * a.batch;
+  const char* tag = sizeof(T) == 2 ? (bm128 ? (bn == 128 ? "gemm_bf16_128x128" : "gemm_bf16_128x64")
+                                            : (bn == 128 ? "gemm_bf16_64x128" : "gemm_bf16_64x64"))
+                                   : (bm128 ? (bn == 128 ? "gemm_f32_128x128" : "gemm_f32_128x64")
+                                            : (bn == 128 ? "gemm_f32_64x128" : "gemm_f32_64x64"));
+  ProfScope prof(tag, flops, bytes, s);
   if (bm128 && bn == 128) {
     dim3 grid(cdiv(a.N, 128), cdiv(a.M, 128), a.batch);
     hipLaunchKernelGGL((gemm_kernel<T, 128, 128, BK>), grid, block, 0, s, a);
@@ -349,6 +357,10 @@ static void gemv_dispatch(const GemvArgs& a, int b0, int nb, hipStream_t s) {
                         hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     attr_set = true;
   }
+  // algorithmic bytes: every weight element once (+ the tiny activation / output vectors)
+  const double wbytes = (double)a.N * a.K * sizeof(T) * (a.W2 ? 2 : 1) + (double)nb * (a.K + a.N) * 4;
+  ProfScope prof(sizeof(T) == 2 ? (a.W2 ? "gemv_bf16_swiglu" : "gemv_bf16") : (a.W2 ? "gemv_f32_swiglu" : "gemv_f32"),
+                 2.0 * nb * a.N * (double)a.K * (a.W2 ? 2 : 1), wbytes, s);
   if (a.W2)
     hipLaunchKernelGGL((gemv_kernel<T, NB, true>), dim3(grid), dim3(512), lds, s, a, b0, nb);
   else

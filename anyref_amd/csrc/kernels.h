@@ -2,9 +2,56 @@
 // activation/weight storage type T: `float` (parity mode, exact-f32 MFMA 16x16x4) or
 // `bf16` (perf mode, MFMA 16x16x32 bf16).  Accumulation and the residual stream are fp32 in both.
 #pragma once
+#include <string>
+#include <utility>
+#include <vector>
+
 #include "common.h"
 
 namespace anyref {
+
+// ---- optional per-kernel timing (bench.py's roofline leg) ---------------------------------------
+// When a Profiler is installed for the calling thread, the GEMM / GEMV / attention launchers
+// bracket every launch with a hipEvent pair on the launch stream and book the elapsed time, the
+// algorithmic FLOPs and the algorithmic bytes under the kernel's tag.
+struct ProfStat {
+  double ms = 0;
+  int64_t count = 0;
+  double flops = 0, bytes = 0;
+};
+class Profiler {
+ public:
+  ~Profiler();
+  void begin(const char* tag, double flops, double bytes, hipStream_t s);
+  void end(hipStream_t s);
+  void collect();  // after the stream has been synchronised
+  void reset();
+  bool on = false;
+  std::vector<std::pair<std::string, ProfStat>> stats() const;
+
+ private:
+  struct Rec {
+    int tag;
+    hipEvent_t a, b;
+    double flops, bytes;
+  };
+  std::vector<Rec> recs_;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pool_;
+  size_t used_ = 0;
+  std::vector<std::string> tags_;
+  std::vector<ProfStat> stats_;
+};
+extern thread_local Profiler* g_prof;
+struct ProfScope {  // RAII bracket used inside the launchers
+  hipStream_t s;
+  bool active;
+  ProfScope(const char* tag, double flops, double bytes, hipStream_t st) : s(st), active(g_prof && g_prof->on) {
+    if (active) g_prof->begin(tag, flops, bytes, s);
+  }
+  ~ProfScope() {
+    if (active) g_prof->end(s);
+  }
+};
 
 // C[dst(m), n] = act(alpha * sum_k A[m,k] W[n,k] + bias[n]) (+ resid[dst(m), n])
 struct GemmArgs {

@@ -52,6 +52,11 @@ class ModelBase {
   virtual void project_audio(hipStream_t s, const float* audio_emb, int n, float* out) = 0;
 
   int64_t device_bytes() const { return bytes_; }
+  void set_seg_range(int lo, int hi) {
+    cfg.seg_lo = lo;
+    cfg.seg_hi = hi;
+  }
+  Profiler prof;
   std::string err;
   int n_unknown = 0;
 

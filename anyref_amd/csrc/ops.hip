@@ -4,6 +4,59 @@
 
 namespace anyref {
 
+thread_local Profiler* g_prof = nullptr;
+
+Profiler::~Profiler() {
+  for (auto& p : pool_) {
+    (void)hipEventDestroy(p.first);
+    (void)hipEventDestroy(p.second);
+  }
+}
+void Profiler::begin(const char* tag, double flops, double bytes, hipStream_t s) {
+  int t = -1;
+  for (size_t i = 0; i < tags_.size(); ++i)
+    if (tags_[i] == tag) t = (int)i;
+  if (t < 0) {
+    tags_.push_back(tag);
+    stats_.push_back(ProfStat());
+    t = (int)tags_.size() - 1;
+  }
+  if (used_ == pool_.size()) {
+    hipEvent_t a, b;
+    HIP_TRY(hipEventCreate(&a));
+    HIP_TRY(hipEventCreate(&b));
+    pool_.push_back({a, b});
+  }
+  Rec r{t, pool_[used_].first, pool_[used_].second, flops, bytes};
+  ++used_;
+  HIP_TRY(hipEventRecord(r.a, s));
+  recs_.push_back(r);
+}
+void Profiler::end(hipStream_t s) { HIP_TRY(hipEventRecord(recs_.back().b, s)); }
+void Profiler::collect() {
+  for (auto& r : recs_) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
+    ProfStat& st = stats_[r.tag];
+    st.ms += ms;
+    st.count += 1;
+    st.flops += r.flops;
+    st.bytes += r.bytes;
+  }
+  recs_.clear();
+  used_ = 0;
+}
+void Profiler::reset() {
+  recs_.clear();
+  used_ = 0;
+  for (auto& s : stats_) s = ProfStat();
+}
+std::vector<std::pair<std::string, ProfStat>> Profiler::stats() const {
+  std::vector<std::pair<std::string, ProfStat>> v;
+  for (size_t i = 0; i < tags_.size(); ++i) v.push_back({tags_[i], stats_[i]});
+  return v;
+}
+
 // ---------------------------------------------------------------------------------------------
 // LayerNorm / RMSNorm: one wave per row, two passes over registers-cached data.
 // ---------------------------------------------------------------------------------------------

@@ -166,6 +166,42 @@ class AnyRefForCausalLM:
     def device_bytes(self) -> int:
         return int(self.lib.anyref_device_bytes(self.h))
 
+    def set_seg_token_idx(self, seg_token_idx):
+        """`seg_token_idx` kwarg of the reference constructor (anyref.py:197-200), changeable later."""
+        self.cfg.seg_token_idx = seg_token_idx
+        lo, hi = self.cfg.seg_range()
+        self._check(self.lib.anyref_set_seg_range(self.h, lo, hi), "set_seg_range")
+
+    # ---- per-kernel timing for bench.py ------------------------------------------------------
+    def profile_enable(self, on: bool):
+        self._check(self.lib.anyref_profile_enable(self.h, int(on)), "profile_enable")
+
+    def profile_read(self):
+        """-> {tag: dict(ms, count, flops, bytes)} of everything timed since profile_enable(True)."""
+        torch.cuda.synchronize(self.device)
+        self._check(self.lib.anyref_profile_collect(self.h), "profile_collect")
+        out, i = {}, 0
+        name = C.create_string_buffer(128)
+        ms, cnt, fl, by = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
+        while self.lib.anyref_profile_read(self.h, i, name, 128, C.byref(ms), C.byref(cnt), C.byref(fl),
+                                           C.byref(by)) == 0:
+            out[name.value.decode()] = dict(ms=ms.value, count=cnt.value, flops=fl.value, bytes=by.value)
+            i += 1
+        return out
+
+    def postprocess(self, low: torch.Tensor, resized_size, original_size) -> torch.Tensor:
+        """`Sam.postprocess_masks` (sam.py:137-172) on low-res logits [n, 4g, 4g] -> [n, H, W]."""
+        low = low.to(self.device, torch.float32).contiguous()
+        n, lh, lw = low.shape
+        out = torch.empty(n, int(original_size[0]), int(original_size[1]), device=self.device, dtype=torch.float32)
+        if n:
+            rc = self.lib.anyref_op_postprocess(self._stream(), _ptr(low), n, lh, lw, self.cfg.sam.img_size,
+                                                int(resized_size[0]), int(resized_size[1]), int(original_size[0]),
+                                                int(original_size[1]), _ptr(out))
+            if rc != 0:
+                raise RuntimeError("postprocess: " + self.lib.anyref_op_last_error().decode())
+        return out
+
     # ---- helpers ---------------------------------------------------------------------------
     def _rows(self, input_ids: torch.Tensor, attention_masks: Optional[torch.Tensor]):
         """-> (ids int64 host [B,Lmax] right-aligned rows, lens int32 [B])."""

@@ -1,0 +1,97 @@
+"""Batch-sharded data parallel inference across the GPUs of one node.
+
+The reference has no multi-GPU inference at all (single process, batch 1:
+`eval_referseg.py:101-106,255`); images are independent (`anyref.py:797-819`), so the path shards
+as pure DP: one process + one `anyref_handle` per GPU, weights replicated, inputs sharded on the
+host, and ONE collective per call — an all-gather of the low-resolution mask logits
+(`[B_local, max_seg, 4g, 4g]` fp32 = 1 MiB per image at SAM-H) plus a tiny all-gather of the
+token ids / [SEG] counts.  Full-resolution masks are re-created from the gathered low-res logits
+by the same bilinear postprocess (bit-identical: the resize is per mask), so the 4 MB/mask
+full-res tensors never cross xGMI.  `backend="nccl"` is RCCL on ROCm; the CPU tests drive the
+same code over gloo.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous block of a global batch of n owned by `rank` (rank r gets [lo, hi))."""
+    per, rem = divmod(n, world)
+    lo = rank * per + min(rank, rem)
+    return lo, lo + per + (1 if rank < rem else 0)
+
+
+def gather_results(low: torch.Tensor, nseg: torch.Tensor, ids: torch.Tensor, ids_len: torch.Tensor,
+                   n_global: int, group=None):
+    """All-gather one rank's results into global-batch order.
+
+    low [b_local, max_seg, L, L] f32, nseg [b_local] i32, ids [b_local, Lout] i64, ids_len [b_local] i32
+    (all on the communication device).  Ranks may own different b_local (ragged tail): rows are
+    padded to ceil(n/world) for the collective and dropped afterwards.
+    """
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    per = -(-n_global // world)
+
+    def padrows(t):
+        if t.shape[0] == per:
+            return t.contiguous()
+        pad = torch.zeros((per - t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        return torch.cat([t, pad], 0).contiguous()
+
+    outs = []
+    for t in (low, nseg, ids, ids_len):
+        t = padrows(t)
+        g = torch.empty((world * per,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(g, t, group=group)
+        outs.append(g)
+    keep = []
+    for r in range(world):
+        lo, hi = shard_range(n_global, r, world)
+        keep += list(range(r * per, r * per + (hi - lo)))
+    keep = torch.tensor(keep, device=low.device)
+    return tuple(o.index_select(0, keep) for o in outs)
+
+
+class DataParallelAnyRef:
+    """Wraps one per-GPU `AnyRefForCausalLM`; `generate` takes the GLOBAL batch on every rank, runs
+    the local shard and returns the gathered global result (same return convention)."""
+
+    def __init__(self, model, group=None):
+        self.model = model
+        self.group = group
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+
+    @torch.no_grad()
+    def generate(self, clip_images, input_ids, sam_images, sam_resized_sizes, height, width, audios=None,
+                 ref_images=None, max_new_tokens=128, attention_masks=None, **kw):
+        n = clip_images.shape[0]
+        lo, hi = shard_range(n, self.rank, self.world)
+        sl = slice(lo, hi)
+        m = self.model
+        pick = lambda x: None if x is None else x[sl]
+        (ids, masks, rest), ex = m.generate(
+            clip_images[sl], input_ids[sl], sam_images[sl], sam_resized_sizes[sl], height[sl], width[sl],
+            audios=pick(audios), ref_images=pick(ref_images), max_new_tokens=max_new_tokens,
+            attention_masks=pick(attention_masks), _return_extras=True)
+        if self.world == 1:
+            return ids, masks, rest
+        Lout = input_ids.shape[1] + max_new_tokens
+        idp = torch.zeros(hi - lo, Lout, dtype=torch.long, device=m.device)
+        idp[:, : ids.shape[1]] = ids
+        low, nseg, gids, glen = gather_results(ex["low_res"], ex["nseg"].to(m.device), idp,
+                                               ex["out_lens"].to(m.device), n, self.group)
+        out_ids = gids[:, : int(glen.max())]
+        if int(nseg.sum()) == 0:
+            return out_ids, None, (None, None, None)
+        # full-resolution logits from the gathered low-res ones (per-mask bilinear, sam.py:137-172)
+        pred = []
+        for b in range(n):
+            k = int(nseg[b])
+            pred.append(m.postprocess(low[b, :k], sam_resized_sizes[b], (int(height[b]), int(width[b]))))
+        return out_ids, pred, (None, None, None)

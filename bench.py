@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of the AnyRef refer-seg forward (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one `generate()` over one batch of synthetic (image, instruction) pairs per GPU:
+CLIP ViT-L/14 -> LLaVA splice -> LLaMA-7B prefill (S=320) + greedy decode (10 new tokens, KV
+cache) -> [SEG] hand-off -> SAM-H image encoder -> mask decoder -> 1024^2 mask logits, with the
+inputs already resident in HBM.  N=1 is BASELINE.json configs[1] (batch 1).  For N>1 (launched by
+torch.distributed.run, one rank per GPU) every rank runs the same per-GPU workload on its own
+images (weak scaling) and the step ends with the RCCL all-gather of the low-res mask logits +
+token ids.
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline     : the dominant kernel of the step (by summed device time), timed live with hipEvent
+                 pairs on the launch stream over the timed region
+  cpu_baseline : the CPU oracle (oracle/anyref_oracle.py, fp32, KV cache on) timed on this host on
+                 one image of the same workload (N=1 only)
+  parity       : mask-logit max-abs-err and greedy-id identity of both arithmetic modes vs that
+                 CPU forward on the same (image, instruction) pair
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from anyref_amd.config import config_7b, config_tiny, IMAGE_TOKEN_INDEX  # noqa: E402
+from anyref_amd.synth import synth_state_dict  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
+PEAK_F32_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0       # HBM3E spec peak
+
+
+def log(*a):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(*a, file=sys.stderr, flush=True)
+
+
+def make_inputs(cfg, B, seed, L_text=63):
+    """SURVEY.md §8d synthetic inputs: BOS, one image placeholder, 63 random ids (L=65, S=320)."""
+    g = torch.Generator().manual_seed(seed)
+    clip = torch.randn(B, 3, cfg.clip.image_size, cfg.clip.image_size, generator=g)
+    sam = torch.randn(B, 3, cfg.sam.img_size, cfg.sam.img_size, generator=g)
+    hi = min(32000, cfg.llm.vocab - 8)
+    ids = torch.stack([torch.cat([torch.tensor([1, IMAGE_TOKEN_INDEX]), torch.randint(3, hi, (L_text,), generator=g)])
+                       for _ in range(B)])
+    return clip, sam, ids
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="c2", choices=["c2", "tiny"])
+    ap.add_argument("--batch-per-gpu", type=int, default=1)
+    ap.add_argument("--max-new-tokens", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log(f"note: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from anyref_amd.model import AnyRefForCausalLM
+    from anyref_amd.parallel import gather_results
+
+    B, T = args.batch_per_gpu, args.max_new_tokens
+    if args.config == "c2":
+        cfg = config_7b()
+        cfg.llm.max_seq = 512
+        S_img = 1024
+    else:
+        cfg = config_tiny()
+        S_img = cfg.sam.img_size
+    t0 = time.time()
+    sd = synth_state_dict(cfg, seed=0, device=dev, dtype=torch.bfloat16)        # identical on every rank
+    clip, sam, ids = make_inputs(cfg, B, seed=1 + rank)
+    clip, sam = clip.to(dev), sam.to(dev)                                          # resident in HBM
+    sizes, H, W = [(S_img, S_img)] * B, [S_img] * B, [S_img] * B
+    model = AnyRefForCausalLM.from_state_dict(cfg, sd, mode="perf", device=local, max_batch=B, max_seg=2)
+    model.config.eos_token_id = None                                               # fixed work: T new tokens
+    torch.cuda.synchronize()
+    log(f"[bench] weights + perf model ready in {time.time() - t0:.1f}s, {model.device_bytes / 2**30:.1f} GiB on device")
+
+    # name the id the random model emits at decode step 3 as [SEG]
+    out_ids, _, _ = model.generate(clip, ids, sam, sizes, H, W, max_new_tokens=T)
+    seg_id = int(out_ids[0, ids.shape[1] + 2])
+    model.set_seg_token_idx(seg_id)
+
+    n_global = B * world
+    Lout = ids.shape[1] + T
+
+    def step():
+        (oids, masks, _), ex = model.generate(clip, ids, sam, sizes, H, W, max_new_tokens=T, _return_extras=True)
+        if world > 1:
+            idp = torch.zeros(B, Lout, dtype=torch.long, device=dev)
+            idp[:, : oids.shape[1]] = oids
+            gather_results(ex["low_res"], ex["nseg"].to(dev), idp, ex["out_lens"].to(dev), n_global)
+        return oids, masks
+
+    for _ in range(args.warmup):
+        step()
+    # pre-pass: which kernel dominates the step?
+    model.profile_enable(True)
+    step()
+    table = model.profile_read()
+    model.profile_enable(False)
+    dom = max(table, key=lambda k: table[k]["ms"]) if table else None
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    model.profile_enable(True)       # hipEvent pairs around the launches during the timed region
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        oids, masks = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    timed = model.profile_read()
+    model.profile_enable(False)
+    tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+    ips = n_global * args.steps / dt
+
+    roofline = None
+    if dom and dom in timed and timed[dom]["count"]:
+        st = timed[dom]
+        sec = st["ms"] / 1e3
+        compute = dom.startswith(("gemm", "attn"))
+        if compute:
+            peak = PEAK_BF16_TFLOPS if "bf16" in dom else PEAK_F32_TFLOPS
+            ach = st["flops"] / sec / 1e12
+            roofline = dict(kernel=dom, bound="mfma", achieved=round(ach, 2), peak=peak, unit="TFLOP/s",
+                            frac=round(ach / peak, 4), traffic=None)
+        else:
+            ach = st["bytes"] / sec / 1e9
+            roofline = dict(kernel=dom, bound="hbm", achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit="GB/s",
+                            frac=round(ach / PEAK_HBM_GBS, 4), traffic=None)
+        roofline.update(launches_per_step=st["count"] // args.steps, avg_launch_us=round(st["ms"] * 1e3 / st["count"], 2),
+                        share_of_step=round(st["ms"] / 1e3 / dt, 3))
+    breakdown = {k: dict(ms_per_step=round(v["ms"], 3), launches=v["count"],
+                         tflops=round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 1),
+                         gbs=round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1)) for k, v in sorted(
+        table.items(), key=lambda kv: -kv[1]["ms"])}
+
+    res = {
+        "metric": "images/sec (1024^2, 7B LLM+ViT-L+SAM-H)" if args.config == "c2" else "images/sec (tiny plumbing config)",
+        "value": round(ips, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": ("C2: LLaVA-7B + CLIP ViT-L/14 + SAM-H refer-seg forward, 1024x1024, S=320 prompt, "
+                                f"{T} new tokens, KV cache" if args.config == "c2" else "C1 tiny plumbing config"),
+                   "batch_per_gpu": B, "global_batch": n_global, "parallelism": f"dp{world}",
+                   "max_new_tokens": T, "weights": "random-init N(0,0.02^2) rounded to bf16"},
+        "roofline": roofline,
+        "kernel_breakdown": breakdown,
+    }
+
+    # ---------------- CPU baseline + parity against it (rank 0, N=1 only) ----------------
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import anyref_oracle as O
+        # the GPU box gives one GPU a share of 16 host cores (of 256 visible); oversubscribing them
+        # makes the fp32 oracle many times slower
+        cores = int(os.environ.get("ANYREF_CPU_THREADS", min(16, os.cpu_count() or 1)))
+        torch.set_num_threads(cores)
+        log("[bench] GPU leg: " + json.dumps({k: res[k] for k in ("value", "ms_per_step", "roofline")}))
+        cfg.seg_token_idx = seg_id
+        t0 = time.time()
+        sd_cpu = {k: v.float().cpu() for k, v in sd.items()}
+        log(f"[bench] weights on host in {time.time() - t0:.1f}s; timing the CPU oracle on 1 image, {cores} threads")
+        t0 = time.time()
+        with torch.no_grad():
+            ref = O.anyref_generate(sd_cpu, cfg, clip[:1].cpu(), [ids[0]], sam[:1].cpu(), sizes[:1], H[:1], W[:1],
+                                    max_new_tokens=T, eos=False, use_cache=True)
+        cpu_s = time.time() - t0
+        res["cpu_baseline"] = {"value": round(1.0 / cpu_s, 5), "unit": "images/sec", "cores": cores, "kind": "port",
+                               "sample": f"1 image of the same workload (full forward, fp32, KV cache on): {cpu_s:.1f}s"}
+        parity = {}
+        same = oids[0].cpu().tolist() == ref["output_ids"][0].tolist()
+        parity["perf"] = {"greedy_ids_identical": same}
+        if same and ref["pred_masks"] is not None and masks is not None:
+            parity["perf"]["mask_logit_max_abs_err"] = float((masks[0].cpu() - ref["pred_masks"][0]).abs().max())
+            parity["perf"]["logit_range"] = float(ref["pred_masks"][0].abs().max())
+        if not args.no_parity:
+            del model
+            torch.cuda.empty_cache()
+            pm = AnyRefForCausalLM.from_state_dict(cfg, sd, mode="parity", device=local, max_batch=1, max_seg=2)
+            pm.config.eos_token_id = None
+            pids, pmasks, _ = pm.generate(clip[:1], ids[:1], sam[:1], sizes[:1], H[:1], W[:1], max_new_tokens=T)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            pm.generate(clip[:1], ids[:1], sam[:1], sizes[:1], H[:1], W[:1], max_new_tokens=T)
+            torch.cuda.synchronize()
+            psame = pids[0].cpu().tolist() == ref["output_ids"][0].tolist()
+            parity["parity"] = {"greedy_ids_identical": psame, "ms_per_image": round((time.perf_counter() - t1) * 1e3, 2)}
+            if psame and pmasks is not None and ref["pred_masks"] is not None:
+                parity["parity"]["mask_logit_max_abs_err"] = float((pmasks[0].cpu() - ref["pred_masks"][0]).abs().max())
+        res["parity"] = parity
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -148,6 +148,21 @@ int anyref_llm_forward(anyref_handle* h, void* stream, const float* embeds, cons
  * out f32 [n, llm_dim] dev, ready to be passed as `extra_embeds`. */
 int anyref_project_audio(anyref_handle* h, void* stream, const float* audio_emb, int n, float* out);
 
+/* Change the inclusive [SEG] id range after creation (`seg_token_idx` kwarg, anyref.py:197-200). */
+int anyref_set_seg_range(anyref_handle* h, int lo, int hi);
+
+/*
+ * Per-kernel timing for the measurement harness (bench.py "roofline"): when enabled, every GEMM /
+ * GEMV / attention launch is bracketed by a hipEvent pair on its launch stream.  After the caller
+ * has synchronised the stream, anyref_profile_collect() books the elapsed times;
+ * anyref_profile_read(idx) returns tag, summed ms, launch count and summed algorithmic FLOPs /
+ * bytes (returns -1 past the last tag).
+ */
+int anyref_profile_enable(anyref_handle* h, int on);
+int anyref_profile_collect(anyref_handle* h);
+int anyref_profile_read(anyref_handle* h, int idx, char* name, int cap, double* ms, int64_t* count,
+                        double* flops, double* bytes);
+
 /* Bytes of HBM the handle holds (weights + workspaces), for sizing reports. */
 int64_t anyref_device_bytes(anyref_handle* h);
 /* Name of the compute mode's arithmetic ("f32" / "bf16"). */
