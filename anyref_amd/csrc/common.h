@@ -63,6 +63,34 @@ typedef __attribute__((ext_vector_type(8))) short short8;   // 8 x bf16 = one MF
 typedef __attribute__((ext_vector_type(4))) float float4v;  // MFMA 16x16 accumulator
 typedef __attribute__((ext_vector_type(4))) uint32_t uint4v;
 
+// 16-byte vector of T -> floats.  NB: __builtin_bit_cast applied directly to an ext_vector element
+// (v[i]) reads element 0 for every i on hipcc/ROCm 7.2; always go through a scalar temporary.
+template <typename T>
+struct Vec16;
+template <>
+struct Vec16<bf16> {
+  static constexpr int N = 8;
+  static __device__ inline void unpack(const uint4v& v, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t u = v[i];
+      f[2 * i] = __builtin_bit_cast(float, u << 16);
+      f[2 * i + 1] = __builtin_bit_cast(float, u & 0xffff0000u);
+    }
+  }
+};
+template <>
+struct Vec16<float> {
+  static constexpr int N = 4;
+  static __device__ inline void unpack(const uint4v& v, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t u = v[i];
+      f[i] = __builtin_bit_cast(float, u);
+    }
+  }
+};
+
 // ---- activations ---------------------------------------------------------------------------
 enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_QUICK_GELU = 3, ACT_SILU = 4 };
 

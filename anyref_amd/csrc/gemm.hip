@@ -198,45 +198,50 @@ template void launch_gemm<bf16>(const GemmArgs&, hipStream_t);
 // with 16-byte loads straight to VGPRs (no LDS round trip for once-read weights:
 // cdna_hip_programming.md §5 "GEMV / M <= 16" row) and reduces across the wave.
 // ---------------------------------------------------------------------------------------------
-template <typename T>
-struct Vec16;
-template <>
-struct Vec16<bf16> {
-  static constexpr int N = 8;
-  static __device__ inline void unpack(const uint4v& v, float* f) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const uint32_t u = v[i];
-      f[2 * i] = __builtin_bit_cast(float, u << 16);
-      f[2 * i + 1] = __builtin_bit_cast(float, u & 0xffff0000u);
-    }
-  }
-};
-template <>
-struct Vec16<float> {
-  static constexpr int N = 4;
-  static __device__ inline void unpack(const uint4v& v, float* f) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      // NB: __builtin_bit_cast applied directly to an ext_vector element (v[i]) reads element 0
-      // for every i on hipcc/ROCm 7.2; go through a scalar temporary.
-      const uint32_t u = v[i];
-      f[i] = __builtin_bit_cast(float, u);
-    }
-  }
-};
-
 template <typename T, int NB, bool DUAL>
 __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int b0, int nb) {
   constexpr int VN = Vec16<T>::N;
-  constexpr int R = DUAL ? 1 : 2;  // weight rows per wave per pass
+  constexpr int R = DUAL ? 1 : 2;   // output rows per wave per pass
+  constexpr int RW = 2;             // weight rows streamed per pass (DUAL: gate row + up row)
+  constexpr int UNR = 4;            // 16-byte loads per row in flight per lane
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* xs = reinterpret_cast<T*>(smem);  // [NB][K]
   __shared__ float red[NB][8];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int K = a.K;
 
-  // stage x (with fused RMSNorm) -------------------------------------------------------------
+  const T* __restrict__ W = reinterpret_cast<const T*>(a.W);
+  const T* __restrict__ W2 = reinterpret_cast<const T*>(a.W2);
+  const int nwaves = gridDim.x * 8;
+  const int gw = blockIdx.x * 8 + wave;
+  const int ngroups = cdiv(a.N, R);
+  constexpr int CH = 64 * VN * UNR;  // K elements one wave sweeps per chunk
+  const int nch = cdiv(K, CH);
+  // Flattened (row group, K chunk) work list of this wave, software-pipelined one chunk deep: the
+  // loads of item t+1 are in flight while item t is multiplied (and while x is being staged).
+  const int my_groups = gw < ngroups ? (ngroups - gw + nwaves - 1) / nwaves : 0;
+  const int items = my_groups * nch;
+  uint4v wcur[UNR][RW], wnxt[UNR][RW];
+  auto load_item = [&](int t, uint4v (&w)[UNR][RW]) {
+    const int g = gw + (t / nch) * nwaves, c = t % nch;
+    const int n0 = g * R;
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int k = c * CH + u * 64 * VN + lane * VN;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int n = n0 + r < a.N ? n0 + r : a.N - 1;
+        w[u][r] = k < K ? __builtin_nontemporal_load(reinterpret_cast<const uint4v*>(W + (int64_t)n * K + k))
+                        : uint4v{0, 0, 0, 0};
+      }
+      if (DUAL)
+        w[u][RW - 1] = k < K ? __builtin_nontemporal_load(reinterpret_cast<const uint4v*>(W2 + (int64_t)n0 * K + k))
+                             : uint4v{0, 0, 0, 0};
+    }
+  };
+  if (items > 0) load_item(0, wcur);
+
+  // stage x (with fused RMSNorm) while the first weight chunk is in flight --------------------
   for (int b = 0; b < nb; ++b) {
     const float* x = a.x + (int64_t)(b0 + b) * a.ldx;
     float scale = 1.f;
@@ -262,83 +267,76 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int b0, int nb) {
   }
   __syncthreads();
 
-  const T* __restrict__ W = reinterpret_cast<const T*>(a.W);
-  const T* __restrict__ W2 = reinterpret_cast<const T*>(a.W2);
-  const int nwaves = gridDim.x * 8;
-  const int gw = blockIdx.x * 8 + wave;
-  const int ngroups = cdiv(a.N, R);
-  for (int g = gw; g < ngroups; g += nwaves) {
-    const int n0 = g * R;
-    float acc[R][NB], acc2[NB];
+  float acc[RW][NB];
 #pragma unroll
-    for (int r = 0; r < R; ++r)
+  for (int r = 0; r < RW; ++r)
 #pragma unroll
-      for (int b = 0; b < NB; ++b) acc[r][b] = 0.f;
+    for (int b = 0; b < NB; ++b) acc[r][b] = 0.f;
+  for (int t = 0; t < items; ++t) {
+    if (t + 1 < items) load_item(t + 1, wnxt);
+    const int c = t % nch;
 #pragma unroll
-    for (int b = 0; b < NB; ++b) acc2[b] = 0.f;
-    for (int k = lane * VN; k < K; k += 64 * VN) {
-      uint4v wv[R], wv2;
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const int n = n0 + r < a.N ? n0 + r : a.N - 1;
-        wv[r] = __builtin_nontemporal_load(reinterpret_cast<const uint4v*>(W + (int64_t)n * K + k));
-      }
-      if (DUAL) wv2 = __builtin_nontemporal_load(reinterpret_cast<const uint4v*>(W2 + (int64_t)n0 * K + k));
-      float xf[NB][VN];
-#pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        if (b < nb) {
-          uint4v xv = *reinterpret_cast<const uint4v*>(&xs[b * K + k]);
-          Vec16<T>::unpack(xv, xf[b]);
-        } else {
-#pragma unroll
-          for (int i = 0; i < VN; ++i) xf[b][i] = 0.f;
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        float wf[VN];
-        Vec16<T>::unpack(wv[r], wf);
-#pragma unroll
-        for (int b = 0; b < NB; ++b)
-#pragma unroll
-          for (int i = 0; i < VN; ++i) acc[r][b] = fmaf(wf[i], xf[b][i], acc[r][b]);
-      }
-      if (DUAL) {
-        float wf[VN];
-        Vec16<T>::unpack(wv2, wf);
-#pragma unroll
-        for (int b = 0; b < NB; ++b)
-#pragma unroll
-          for (int i = 0; i < VN; ++i) acc2[b] = fmaf(wf[i], xf[b][i], acc2[b]);
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < R; ++r)
-#pragma unroll
-      for (int b = 0; b < NB; ++b) acc[r][b] = wave_sum(acc[r][b]);
-    if (DUAL)
-#pragma unroll
-      for (int b = 0; b < NB; ++b) acc2[b] = wave_sum(acc2[b]);
-    if (lane == 0) {
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const int n = n0 + r;
-        if (n >= a.N) continue;
+    for (int u = 0; u < UNR; ++u) {
+      const int k = c * CH + u * 64 * VN + lane * VN;
+      if (k < K) {
+        float xf[NB][VN];
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-          if (b >= nb) continue;
-          float v = acc[r][b];
-          if (a.bias) v += a.bias[n];
-          if (DUAL)
-            v = apply_act(v, ACT_SILU) * acc2[b];
-          else
-            v = apply_act(v, a.act);
-          const int64_t o = (int64_t)(b0 + b) * a.ldy + n;
-          if (a.resid) v += a.resid[o];
-          a.y[o] = v;
+          if (b < nb) {
+            const uint4v xv = *reinterpret_cast<const uint4v*>(&xs[b * K + k]);
+            Vec16<T>::unpack(xv, xf[b]);
+          } else {
+#pragma unroll
+            for (int i = 0; i < VN; ++i) xf[b][i] = 0.f;
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+          float wf[VN];
+          Vec16<T>::unpack(wcur[u][r], wf);
+#pragma unroll
+          for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int i = 0; i < VN; ++i) acc[r][b] = fmaf(wf[i], xf[b][i], acc[r][b]);
         }
       }
+    }
+    if (c == nch - 1) {  // row group finished: reduce across the wave and store
+      const int n0 = (gw + (t / nch) * nwaves) * R;
+#pragma unroll
+      for (int r = 0; r < RW; ++r)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[r][b] = wave_sum(acc[r][b]);
+      if (lane == 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int n = n0 + r;
+          if (n >= a.N) continue;
+#pragma unroll
+          for (int b = 0; b < NB; ++b) {
+            if (b >= nb) continue;
+            float v = acc[r][b];
+            if (a.bias) v += a.bias[n];
+            if (DUAL)
+              v = apply_act(v, ACT_SILU) * acc[RW - 1][b];
+            else
+              v = apply_act(v, a.act);
+            const int64_t o = (int64_t)(b0 + b) * a.ldy + n;
+            if (a.resid) v += a.resid[o];
+            a.y[o] = v;
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < RW; ++r)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[r][b] = 0.f;
+    }
+    if (t + 1 < items) {
+#pragma unroll
+      for (int u = 0; u < UNR; ++u)
+#pragma unroll
+        for (int r = 0; r < RW; ++r) wcur[u][r] = wnxt[u][r];
     }
   }
 }

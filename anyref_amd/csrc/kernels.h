@@ -125,10 +125,24 @@ struct AttnArgs {
   const float* rel_h = nullptr;  // f32 [B,H,Sq,kh] or null
   const float* rel_w = nullptr;  // f32 [B,H,Sq,kw]
   int kh = 0, kw = 0;
+  // alternative bias source (SAM encoder hot path): P[h][b*Sq+i][0:Np) = q_i . tab_h[j], [Np:2Np) = q_i . tab_w[j]
+  // produced by one batched MFMA GEMM; the kernel applies the relative shift itself:
+  // rel_h[i,ky] = P[..][y_i - ky + kh - 1], rel_w[i,kx] = P[..][Np + x_i - kx + kw - 1]   (get_rel_pos)
+  const float* rel_p = nullptr;
+  int64_t rel_hs = 0;  // head stride of P (elements)
+  int rel_ld = 0;      // row stride of P = 2*Np
   int o_f32 = 0;  // 1: O is f32 instead of T (decode step feeds the f32 GEMV)
 };
 template <typename T>
 void launch_attention(const AttnArgs& a, hipStream_t s);
+
+// Decode-step attention for ONE new token per sequence, fused with RoPE and the KV-cache append:
+// qkv f32 [B,3*H*hd] (this step's projections) -> rotates q,k at pos[b], appends k,v to the cache,
+// attends over keys [0, pos[b]] and writes out f32 [B,H*hd].  Returns false if hd is unsupported
+// (caller falls back to rope_cache + the generic attention kernel).
+template <typename T>
+bool launch_decode_attn(const float* qkv, int B, int H, int hd, const int* pos, const float* cs_tab, void* kc,
+                        void* vc, int maxS, float scale, float* out, void* q_keep, hipStream_t s);
 
 // Head-mean softmax row of ONE query per batch element over keys [0, kv_len):
 // out[b, j] = mean_h softmax_j(scale * q[b,h].k[b,j,h])   (anyref.py:748-749)

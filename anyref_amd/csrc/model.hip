@@ -180,6 +180,12 @@ class Model : public ModelBase {
                 const std::vector<int>& seg_pos, const std::vector<int>& reph_s, const int32_t* resized_hw,
                 const int32_t* orig_hw, int32_t* out_nseg, float* out_masks, int64_t out_masks_cap,
                 int64_t* mask_offsets, float* out_low);
+  // SAM image encoder on a second stream: it depends on nothing but the image, is MFMA-bound, and
+  // overlaps the HBM-bound LLM decode (fork at the start of a call, join before the mask decoder).
+  void fork_sam(hipStream_t s, const float* sam_images, int B);
+  hipStream_t s2_ = nullptr;
+  hipEvent_t ev_fork_ = nullptr, ev_sam_ = nullptr;
+  bool sam_forked_ = false;
   int splice_inputs(hipStream_t s, const int64_t* input_ids, const int32_t* lens, int B, int Lmax,
                     const float* extra_embeds, const int32_t* extra_slots, int n_extra,
                     std::vector<int>& slen, std::vector<int>& img_pos);
@@ -231,7 +237,7 @@ class Model : public ModelBase {
   struct SamBlock {
     Affine ln1, ln2;
     Lin<T> qkv, proj, lin1, lin2;
-    float *rel_h = nullptr, *rel_w = nullptr;
+    Lin<T> rel;  // [2*Np, hd]: rows [0,2sz-1) = rel_pos_h, rows [Np, Np+2sz-1) = rel_pos_w, Np = 2*sz
     bool global = false;
   };
   Lin<T> sam_patch_;
@@ -508,8 +514,15 @@ void Model<T>::finalize() {
       const int sz = L.global ? g : ws;
       if (raw(bp + "attn.rel_pos_h").numel() != (int64_t)(2 * sz - 1) * hd)
         throw std::runtime_error("rel_pos table of " + bp + " is not (2*size-1) x head_dim (interpolation unsupported)");
-      L.rel_h = own_f32(bp + "attn.rel_pos_h");
-      L.rel_w = own_f32(bp + "attn.rel_pos_w");
+      if (raw(bp + "attn.rel_pos_w").numel() != (int64_t)(2 * sz - 1) * hd)
+        throw std::runtime_error("rel_pos_w table of " + bp + " has the wrong shape");
+      const int Np = 2 * sz;
+      L.rel.n = 2 * Np;
+      L.rel.k = hd;
+      L.rel.w = talloc<T>((size_t)2 * Np * hd);
+      HIP_TRY(hipMemset(L.rel.w, 0, (size_t)2 * Np * hd * sizeof(T)));
+      pack_rows(L.rel.w, 0, bp + "attn.rel_pos_h", 2 * sz - 1, hd, hd);
+      pack_rows(L.rel.w, Np, bp + "attn.rel_pos_w", 2 * sz - 1, hd, hd);
     }
     neck0_ = pack_linear(p + "neck.0.weight", "", C, D);
     neck1_ = affine(p + "neck.1");
@@ -557,10 +570,9 @@ void Model<T>::finalize() {
     s_qkv_ = talloc<T>(RW * 3 * D);
     s_att_ = talloc<T>(RW * D);
     s_mlp_ = talloc<T>(RT * c.sam_mlp_ratio * D);
-    const size_t rel_g = (size_t)MB * c.sam_heads * g * g * g;
-    const size_t rel_w = (size_t)MB * sam_nw_ * sam_nw_ * c.sam_heads * ws * ws * ws;
+    const size_t rel_g = (size_t)MB * c.sam_heads * g * g * 4 * g;          // [H][B*g*g][2*Np], Np = 2g
+    const size_t rel_w = (size_t)MB * sam_wrows_ * c.sam_heads * 4 * ws;     // [H][B*wrows][2*Np], Np = 2ws
     s_relh_ = talloc<float>(std::max(rel_g, rel_w));
-    s_relw_ = talloc<float>(std::max(rel_g, rel_w));
     s_n0_ = talloc<float>(RT * C);
     s_n1_ = talloc<T>(RT * C);
     s_col3_ = talloc<T>(RT * 9 * C);
@@ -670,9 +682,21 @@ void Model<T>::finalize() {
     m_masks_ = talloc<float>((size_t)n * nt * 16 * NK);
     m_iou_ = talloc<float>((size_t)n * nt);
   }
+  HIP_TRY(hipStreamCreateWithFlags(&s2_, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&ev_sam_, hipEventDisableTiming));
   HIP_TRY(hipDeviceSynchronize());
   drop_raw();
   finalized_ = true;
+}
+
+template <typename T>
+void Model<T>::fork_sam(hipStream_t s, const float* sam_images, int B) {
+  HIP_TRY(hipEventRecord(ev_fork_, s));
+  HIP_TRY(hipStreamWaitEvent(s2_, ev_fork_, 0));
+  sam_encoder(s2_, sam_images, B, sam_emb_);
+  HIP_TRY(hipEventRecord(ev_sam_, s2_));
+  sam_forked_ = true;
 }
 
 template <typename T>
@@ -789,17 +813,20 @@ void Model<T>::llm_decode_step(hipStream_t s, int B, bool keep_q) {
     g.x = d_x_; g.ldx = H; g.gain = L.in_norm.g; g.eps = c.llm_rms_eps; g.W = L.qkv.w; g.y = d_qkv_;
     g.ldy = 3 * H; g.B = B; g.N = 3 * H; g.K = H;
     launch_gemv<T>(g, s);
-    launch_rope_cache_f32<T>(d_qkv_, B, nh, hd, pos_dev_, rope_tab_, d_q_, kc, vc, S,
-                             (keep_q && i == nl - 1) ? q_last_ : nullptr, s);
-    AttnArgs a;
-    a.Q = d_q_; a.K = kc; a.V = vc; a.O = d_att_; a.o_f32 = 1;
-    a.q_bs = H; a.q_rs = H; a.q_hs = hd;
-    a.k_bs = a.v_bs = (int64_t)S * H; a.k_rs = a.v_rs = H; a.k_hs = a.v_hs = hd;
-    a.o_bs = H; a.o_rs = H; a.o_hs = hd;
-    a.B = B; a.H = nh; a.Sq = 1; a.Sk = S; a.hd = hd;
-    a.scale = 1.f / sqrtf((float)hd);
-    a.kv_len = kvlen_dev_;
-    launch_attention<T>(a, s);
+    T* qk = (keep_q && i == nl - 1) ? q_last_ : nullptr;
+    if (!launch_decode_attn<T>(d_qkv_, B, nh, hd, pos_dev_, rope_tab_, kc, vc, S, 1.f / sqrtf((float)hd), d_att_, qk,
+                               s)) {
+      launch_rope_cache_f32<T>(d_qkv_, B, nh, hd, pos_dev_, rope_tab_, d_q_, kc, vc, S, qk, s);
+      AttnArgs a;
+      a.Q = d_q_; a.K = kc; a.V = vc; a.O = d_att_; a.o_f32 = 1;
+      a.q_bs = H; a.q_rs = H; a.q_hs = hd;
+      a.k_bs = a.v_bs = (int64_t)S * H; a.k_rs = a.v_rs = H; a.k_hs = a.v_hs = hd;
+      a.o_bs = H; a.o_rs = H; a.o_hs = hd;
+      a.B = B; a.H = nh; a.Sq = 1; a.Sk = S; a.hd = hd;
+      a.scale = 1.f / sqrtf((float)hd);
+      a.kv_len = kvlen_dev_;
+      launch_attention<T>(a, s);
+    }
     GemvArgs o;
     o.x = d_att_; o.ldx = H; o.W = L.o.w; o.y = d_x_; o.resid = d_x_; o.ldy = H; o.B = B; o.N = H; o.K = H;
     launch_gemv<T>(o, s);
@@ -878,11 +905,20 @@ void Model<T>::sam_encoder(hipStream_t s, const float* images, int B, float* out
     a.q_rs = a.k_rs = a.v_rs = 3 * D; a.o_rs = D;
     a.H = nh; a.hd = hd; a.scale = 1.f / sqrtf((float)hd);
     a.Q = s_qkv_; a.K = s_qkv_ + D; a.V = s_qkv_ + 2 * D; a.O = s_att_;
-    a.rel_h = s_relh_; a.rel_w = s_relw_;
+    // decomposed rel-pos bias: P = q . [rel_pos_h | rel_pos_w]^T for every head in ONE batched MFMA GEMM
+    // (batch = heads, A = the q columns of the fused qkv buffer); the attention kernel applies the shift.
+    auto rel_gemm = [&](int rows) {
+      GemmArgs r;
+      r.A = s_qkv_; r.lda = 3 * D; r.sA = hd; r.W = L.rel.w; r.ldw = hd; r.sW = 0;
+      r.C = s_relh_; r.ldc = L.rel.n; r.sC = (int64_t)rows * L.rel.n; r.M = rows; r.N = L.rel.n; r.K = hd;
+      r.c_f32 = 1; r.batch = nh;
+      launch_gemm<T>(r, s);
+      a.rel_p = s_relh_; a.rel_ld = L.rel.n; a.rel_hs = (int64_t)rows * L.rel.n;
+    };
     if (L.global) {
       norm(s, s_x_, D, L.ln1, s_hglob_, D, RT, D, 1e-6f, false);
       gemm(s, s_hglob_, D, L.qkv, s_qkv_, 3 * D, RT, ACT_NONE, false);
-      launch_rel_pos<T>(s_qkv_, (int64_t)NT * 3 * D, 3 * D, hd, L.rel_h, L.rel_w, B, nh, g, hd, s_relh_, s_relw_, s);
+      rel_gemm(RT);
       a.q_bs = a.k_bs = a.v_bs = (int64_t)NT * 3 * D; a.o_bs = (int64_t)NT * D;
       a.B = B; a.Sq = NT; a.Sk = NT; a.kh = g; a.kw = g;
       launch_attention<T>(a, s);
@@ -891,7 +927,7 @@ void Model<T>::sam_encoder(hipStream_t s, const float* images, int B, float* out
       const int RW = B * WR, S2 = ws * ws;
       norm(s, s_x_, D, L.ln1, s_hwin_, D, RT, D, 1e-6f, false, false, tok2win_);
       gemm(s, s_hwin_, D, L.qkv, s_qkv_, 3 * D, RW, ACT_NONE, false);
-      launch_rel_pos<T>(s_qkv_, (int64_t)S2 * 3 * D, 3 * D, hd, L.rel_h, L.rel_w, B * nW, nh, ws, hd, s_relh_, s_relw_, s);
+      rel_gemm(RW);
       a.q_bs = a.k_bs = a.v_bs = (int64_t)S2 * 3 * D; a.o_bs = (int64_t)S2 * D;
       a.B = B * nW; a.Sq = S2; a.Sk = S2; a.kh = ws; a.kw = ws;
       launch_attention<T>(a, s);
@@ -1106,6 +1142,11 @@ void Model<T>::run_tail(hipStream_t s, const float* sam_images, int B, const std
     off += (int64_t)out_nseg[b] * orig_hw[2 * b] * orig_hw[2 * b + 1];
   }
   if (off > out_masks_cap) throw std::runtime_error("out_masks capacity too small");
+  if (sam_forked_) {  // join: everything after this point on `s` sees the image embeddings
+    HIP_TRY(hipStreamWaitEvent(s, ev_sam_, 0));
+  }
+  const bool sam_ready = sam_forked_;
+  sam_forked_ = false;
   if (nseg == 0) return;
   HIP_TRY(hipMemcpyAsync(idx_a_, seg_b.data(), nseg * 4, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(idx_b_, seg_pos.data(), nseg * 4, hipMemcpyHostToDevice, s));
@@ -1133,7 +1174,7 @@ void Model<T>::run_tail(hipStream_t s, const float* sam_images, int B, const std
   }
   gemmf(s, seg_h_, H, fc1_, seg_t_, H, nseg, ACT_RELU);
   gemmf(s, seg_t_, H, fc2_, pred_emb_, c.out_dim, nseg, ACT_NONE);
-  sam_encoder(s, sam_images, B, sam_emb_);
+  if (!sam_ready) sam_encoder(s, sam_images, B, sam_emb_);
   const int NK = sam_g_ * sam_g_, C = c.sam_out_chans, L = 4 * sam_g_;
   int row = 0;
   for (int b = 0; b < B; ++b) {
@@ -1166,6 +1207,7 @@ void Model<T>::generate(hipStream_t s, const float* clip_images, const float* sa
   const int H = c.llm_dim, S = c.llm_max_seq, n_img = clip_n_;
   const bool keep_q = c.rephrase_weight > 0.f;
 
+  fork_sam(s, sam_images, B);
   clip_tower(s, clip_images, B);
   std::vector<int> slen, img_pos;
   const int Sp = splice_inputs(s, input_ids, lens, B, Lmax, extra_embeds, extra_slots, n_extra, slen, img_pos);
@@ -1247,6 +1289,7 @@ void Model<T>::forward_teacher(hipStream_t s, const float* clip_images, const fl
   if (B <= 0 || B > c.max_batch) throw std::runtime_error("batch exceeds max_batch");
   const int H = c.llm_dim, S = c.llm_max_seq, n_img = clip_n_;
   const bool keep_q = c.rephrase_weight > 0.f;
+  fork_sam(s, sam_images, B);
   clip_tower(s, clip_images, B);
   std::vector<int> slen, img_pos;
   const int Sp = splice_inputs(s, input_ids, lens, B, Lmax, extra_embeds, extra_slots, n_extra, slen, img_pos);
