@@ -1,0 +1,121 @@
+"""CPU-side tests (no GPU): the C-ABI library loads and exports every symbol the headers
+declare, the headers and the ctypes table agree, config/weight-name plumbing, and the DP
+shard/gather logic over gloo with world_size 2."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _build():
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    g.build()
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    _build()
+    from anyref_amd import _lib
+    lib = _lib.load()
+    declared = set()
+    for hdr in ("anyref_hip.h", "anyref_hip_ops.h"):
+        txt = open(os.path.join(ROOT, "include", hdr)).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        declared |= set(re.findall(r"\b(anyref_[a-z0-9_]+)\s*\(", txt))
+    assert declared, "no declarations parsed"
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/ but not exported"
+    assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
+
+
+def test_config_struct_matches_header_field_order():
+    from anyref_amd import _lib
+    txt = open(os.path.join(ROOT, "include", "anyref_hip.h")).read()
+    body = txt[txt.index("typedef struct anyref_config {"): txt.index("} anyref_config;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split("{", 1)[1].split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        for part in decl.split(None, 1)[1].split(","):
+            names.append(part.strip().split("[")[0])
+    assert names == [f[0] for f in _lib.AnyrefConfig._fields_]
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    _build()
+    from anyref_amd.config import config_tiny
+    from anyref_amd.model import AnyRefForCausalLM
+    with pytest.raises(RuntimeError):
+        AnyRefForCausalLM(config_tiny())
+
+
+def test_weight_names_cover_reference_keys():
+    from anyref_amd.config import config_7b
+    from anyref_amd.synth import weight_shapes
+    names = {n for n, _, _ in weight_shapes(config_7b())}
+    for must in ("model.visual_model.image_encoder.blocks.31.attn.rel_pos_h",
+                 "model.visual_model.mask_decoder.output_hypernetworks_mlps.3.layers.2.weight",
+                 "model.visual_model.prompt_encoder.pe_layer.positional_encoding_gaussian_matrix",
+                 "model.text_hidden_fcs.0.0.weight", "model.text_hidden_fcs.0.2.bias", "model.audio_projector.weight",
+                 "model.layers.31.mlp.down_proj.weight", "lm_head.weight", "model.mm_projector.weight",
+                 "model.vision_tower.vision_tower.vision_model.encoder.layers.22.self_attn.q_proj.weight"):
+        assert must in names, must
+    # hidden_states[-2] of a 24-layer tower: layer 23 is never run, so never requested
+    assert not any(".encoder.layers.23." in n for n in names)
+
+
+def test_shard_range_partitions_exactly():
+    from anyref_amd.parallel import shard_range
+    for n in (1, 7, 32, 33):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from anyref_amd.parallel import gather_results, shard_range
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:" + sys.argv[2], rank=rank, world_size=world)
+n, L = int(sys.argv[3]), 8
+g = torch.Generator().manual_seed(0)
+low_all = torch.randn(n, 2, L, L, generator=g)
+nseg_all = torch.randint(0, 3, (n,), generator=g).int()
+ids_all = torch.randint(0, 100, (n, 11), generator=g)
+len_all = torch.randint(5, 11, (n,), generator=g).int()
+lo, hi = shard_range(n, rank, world)
+low, nseg, ids, ln = gather_results(low_all[lo:hi], nseg_all[lo:hi], ids_all[lo:hi], len_all[lo:hi], n)
+assert torch.equal(low, low_all) and torch.equal(nseg, nseg_all) and torch.equal(ids, ids_all) and torch.equal(ln, len_all)
+dist.barrier()
+dist.destroy_process_group()
+print("OK", rank)
+'''
+
+
+@pytest.mark.parametrize("n", [4, 5])
+def test_dp_gather_gloo_world2(tmp_path, n):
+    """every rank ends up with the global batch in order, ragged tail included"""
+    script = tmp_path / "w.py"
+    script.write_text(_WORKER)
+    port = str(29500 + os.getpid() % 2000 + n)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT, port, str(n)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    for p in procs:
+        out, _ = p.communicate(timeout=120)
+        assert p.returncode == 0 and "OK" in out, out
