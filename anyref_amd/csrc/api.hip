@@ -122,6 +122,13 @@ int anyref_profile_enable(anyref_handle* h, int on) {
   });
 }
 
+int anyref_profile_config(anyref_handle* h, const char* only_tag, int sample_every) {
+  GUARD(h, {
+    h->m->prof.filter = only_tag ? only_tag : "";
+    h->m->prof.sample_every = sample_every > 1 ? sample_every : 1;
+  });
+}
+
 int anyref_profile_collect(anyref_handle* h) { GUARD(h, h->m->prof.collect()); }
 
 int anyref_profile_read(anyref_handle* h, int idx, char* name, int cap, double* ms, int64_t* count, double* flops,

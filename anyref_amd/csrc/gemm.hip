@@ -9,6 +9,7 @@
 //
 // Structure: 256 threads = 4 waves as 2x2, block tile BM x BN x BK, register-prefetched global
 // loads (issue tile t+1 before computing tile t, write to LDS after the barrier: T14 split).
+#include <cstdlib>
 #include <stdexcept>
 #include "kernels.h"
 
@@ -39,6 +40,40 @@ struct Mma<float> {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
   }
 };
+
+// Shared epilogue: bias, activation, residual, row map, typed store.
+template <typename T, int BM, int BN>
+__device__ inline void gemm_epilogue(const GemmArgs& a, float4v (&acc)[BM / 32][BN / 32], int m0, int n0, int z,
+                                     int lane, int wr, int wc) {
+  constexpr int MI = BM / 32, NI = BN / 32;
+  const float* bias = a.bias ? a.bias + (int64_t)z * a.sBias : nullptr;
+  const float* resid = a.resid ? a.resid + (int64_t)z * a.sR : nullptr;
+  float* Cf = reinterpret_cast<float*>(a.C) + (int64_t)z * a.sC;
+  T* Ct = reinterpret_cast<T*>(a.C) + (int64_t)z * a.sC;
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + wr * (BM / 2) + i * 16 + (lane >> 4) * 4 + r;
+      if (m >= a.M) continue;
+      const int dm = a.row_map ? a.row_map[m] : m;
+      if (dm < 0) continue;
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int n = n0 + wc * (BN / 2) + j * 16 + (lane & 15);
+        if (n >= a.N) continue;
+        float v = acc[i][j][r] * a.alpha;
+        if (bias) v += bias[n];
+        v = apply_act(v, a.act);
+        if (resid) v += resid[(int64_t)dm * a.ldr + n];
+        if (a.c_f32)
+          Cf[(int64_t)dm * a.ldc + n] = v;
+        else
+          Ct[(int64_t)dm * a.ldc + n] = from_f32<T>(v);
+      }
+    }
+  }
+}
 
 template <typename T, int BM, int BN, int BK>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
@@ -119,34 +154,124 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
     __syncthreads();
   }
 
-  // ---- epilogue --------------------------------------------------------------------------
-  const float* bias = a.bias ? a.bias + (int64_t)z * a.sBias : nullptr;
-  const float* resid = a.resid ? a.resid + (int64_t)z * a.sR : nullptr;
-  float* Cf = reinterpret_cast<float*>(a.C) + (int64_t)z * a.sC;
-  T* Ct = reinterpret_cast<T*>(a.C) + (int64_t)z * a.sC;
+  gemm_epilogue<T, BM, BN>(a, acc, m0, n0, z, lane, wr, wc);
+}
+
+// ---------------------------------------------------------------------------------------------
+// bf16 main GEMM: BM x 128 x 64 tile, operands staged HBM -> LDS by global_load_lds (16 B/lane,
+// no VGPR round trip), two LDS buffers, one barrier per K tile (guide §5.5 "minimum 2-phase").
+// LDS rows are 128 B; a wave-instruction fills 8 rows linearly, so the bank-conflict swizzle
+// (16-B chunk index ^ (row & 7)) is applied to the per-lane SOURCE address and again on the
+// fragment read (guide rule 21).  Rows past M / N are clamped to the last valid row (their
+// results are never stored); K must be a multiple of 64 here (launcher falls back otherwise).
+// Tiles are walked M-fastest inside an XCD-contiguous chunk of the grid so that the blocks that
+// share a weight panel hit the same L2 (T1, bijective remap).
+// ---------------------------------------------------------------------------------------------
+template <int BM>
+__global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs a, int tiles_m, int tiles_n) {
+  constexpr int BN = 128, BK = 64;
+  constexpr int MI = BM / 32, NI = BN / 32;
+  constexpr int A_INST = BM / 8, B_INST = BN / 8, PER_WAVE = (A_INST + B_INST) / 4;
+  constexpr int TILE_A = BM * BK, TILE_B = BN * BK;  // elements
+  __shared__ __attribute__((aligned(16))) bf16 lds[2 * (TILE_A + TILE_B)];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  // XCD-aware, bijective block remap; then M-fastest tile order
+  const int nwg = tiles_m * tiles_n;
+  int id = blockIdx.x;
+  {
+    const int q = nwg / 8, r = nwg % 8, xcd = id % 8;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + id / 8;
+  }
+  const int pm = id % tiles_m, pn = id / tiles_m;
+  const int m0 = pm * BM, n0 = pn * BN;
+  const int z = blockIdx.z;
+  const bf16* __restrict__ A = reinterpret_cast<const bf16*>(a.A) + (int64_t)z * a.sA;
+  const bf16* __restrict__ W = reinterpret_cast<const bf16*>(a.W) + (int64_t)z * a.sW;
+
+  // per-lane source pointers of this wave's staging instructions (tile 0), advanced by BK per tile
+  const bf16* src[PER_WAVE];
+  int dst[PER_WAVE];  // LDS element offset of the instruction's 1 KiB destination within a buffer
 #pragma unroll
-  for (int i = 0; i < MI; ++i) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int m = m0 + wr * (BM / 2) + i * 16 + (lane >> 4) * 4 + r;
-      if (m >= a.M) continue;
-      const int dm = a.row_map ? a.row_map[m] : m;
-      if (dm < 0) continue;
-#pragma unroll
-      for (int j = 0; j < NI; ++j) {
-        const int n = n0 + wc * (BN / 2) + j * 16 + (lane & 15);
-        if (n >= a.N) continue;
-        float v = acc[i][j][r] * a.alpha;
-        if (bias) v += bias[n];
-        v = apply_act(v, a.act);
-        if (resid) v += resid[(int64_t)dm * a.ldr + n];
-        if (a.c_f32)
-          Cf[(int64_t)dm * a.ldc + n] = v;
-        else
-          Ct[(int64_t)dm * a.ldc + n] = from_f32<T>(v);
-      }
+  for (int i = 0; i < PER_WAVE; ++i) {
+    const int inst = wave + 4 * i;  // A instructions first, then B
+    const bool isA = inst < A_INST;
+    const int li = isA ? inst : inst - A_INST;
+    const int r = li * 8 + (lane >> 3), pc = lane & 7, lc = pc ^ (r & 7);
+    if (isA) {
+      int gm = m0 + r;
+      gm = gm < a.M ? gm : a.M - 1;
+      src[i] = A + (int64_t)gm * a.lda + lc * 8;
+      dst[i] = li * 512;
+    } else {
+      int gn = n0 + r;
+      gn = gn < a.N ? gn : a.N - 1;
+      src[i] = W + (int64_t)gn * a.ldw + lc * 8;
+      dst[i] = TILE_A + li * 512;
     }
   }
+  auto stage = [&](int buf) {
+    bf16* base = lds + buf * (TILE_A + TILE_B);
+#pragma unroll
+    for (int i = 0; i < PER_WAVE; ++i) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src[i],
+                                       (__attribute__((address_space(3))) void*)(base + dst[i]), 16, 0, 0);
+      src[i] += BK;
+    }
+  };
+
+  float4v acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
+
+  const int nt = a.K / BK;
+  stage(0);
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < nt) stage(buf ^ 1);
+    const bf16* As = lds + buf * (TILE_A + TILE_B);
+    const bf16* Bs = As + TILE_A;
+#pragma unroll
+    for (int ks = 0; ks < BK / 32; ++ks) {
+      const int pc = ((ks * 4 + (lane >> 4)) ^ (lane & 7)) * 8;  // swizzled 16-B chunk of this lane
+      short8 af[MI], bfr[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+        af[i] = *reinterpret_cast<const short8*>(As + (wr * (BM / 2) + i * 16 + (lane & 15)) * BK + pc);
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+        bfr[j] = *reinterpret_cast<const short8*>(Bs + (wc * (BN / 2) + j * 16 + (lane & 15)) * BK + pc);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  gemm_epilogue<bf16, BM, BN>(a, acc, m0, n0, z, lane, wr, wc);
+}
+
+static bool launch_gemm_glds(const GemmArgs& a, hipStream_t s) {
+  // measured on MI355X (scratch/bench_gemm.py): the glds kernel wins when at least one full wave of
+  // 128x128 tiles exists; below that the register-staged kernel's smaller tiles fill the chip better
+  if (a.K % 64 || a.K < 64) return false;
+  const int tn = cdiv(a.N, 128);
+  const bool bm128 = true;
+  if ((int64_t)cdiv(a.M, 128) * tn * a.batch < 256) return false;
+  const int tm = cdiv(a.M, 128);
+  const double flops = 2.0 * a.M * a.N * (double)a.K * a.batch;
+  const double bytes = ((double)a.M * a.K + (double)a.N * a.K) * 2 * a.batch + (double)a.M * a.N * (a.c_f32 ? 4 : 2) * a.batch;
+  ProfScope prof(bm128 ? "gemm_bf16_glds_128x128" : "gemm_bf16_glds_64x128", flops, bytes, s);
+  dim3 grid(tm * tn, 1, a.batch);
+  if (bm128)
+    hipLaunchKernelGGL((gemm_glds_kernel<128>), grid, dim3(256), 0, s, a, tm, tn);
+  else
+    hipLaunchKernelGGL((gemm_glds_kernel<64>), grid, dim3(256), 0, s, a, tm, tn);
+  return true;
 }
 
 template <typename T>
@@ -157,6 +282,8 @@ void launch_gemm(const GemmArgs& a, hipStream_t s) {
   if (a.K % VEC || a.lda % VEC || a.ldw % VEC || ((uintptr_t)a.A & 15) || ((uintptr_t)a.W & 15) ||
       (a.sA % VEC) || (a.sW % VEC))
     throw std::runtime_error("gemm: K/lda/ldw must be multiples of 16 bytes and operands 16-byte aligned");
+  static const bool force_old = getenv("ANYREF_GEMM_OLD") != nullptr;  // A/B switch for microbenchmarks
+  if (sizeof(T) == 2 && a.M >= 48 && !force_old && launch_gemm_glds(a, s)) return;
   // tile choice: fewest padded rows first, then enough workgroups to cover the 256 CUs
   const int waste128 = cdiv(a.M, 128) * 128 - a.M, waste64 = cdiv(a.M, 64) * 64 - a.M;
   bool bm128 = waste128 <= waste64 + 16;
@@ -346,7 +473,8 @@ static void gemv_dispatch(const GemvArgs& a, int b0, int nb, hipStream_t s) {
   const size_t lds = (size_t)NB * a.K * sizeof(T);
   if (lds > 150 * 1024) throw std::runtime_error("gemv: K too large for the LDS activation stage");
   // one or two 8-wave workgroups per CU depending on the LDS the activation stage needs
-  const int grid = 256 * (lds > 76 * 1024 ? 1 : 2);
+  static const int grid_mul = getenv("ANYREF_GEMV_GRID") ? atoi(getenv("ANYREF_GEMV_GRID")) : 2;  // tuning knob
+  const int grid = 256 * (lds > 76 * 1024 ? 1 : grid_mul);
   static bool attr_set = false;  // per instantiation
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_kernel<T, NB, true>),

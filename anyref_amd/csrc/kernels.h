@@ -2,6 +2,7 @@
 // activation/weight storage type T: `float` (parity mode, exact-f32 MFMA 16x16x4) or
 // `bf16` (perf mode, MFMA 16x16x32 bf16).  Accumulation and the residual stream are fp32 in both.
 #pragma once
+#include <cstdlib>
 #include <string>
 #include <utility>
 #include <vector>
@@ -22,11 +23,14 @@ struct ProfStat {
 class Profiler {
  public:
   ~Profiler();
-  void begin(const char* tag, double flops, double bytes, hipStream_t s);
+  // returns false when this launch is filtered out / not sampled (then end() must not be called)
+  bool begin(const char* tag, double flops, double bytes, hipStream_t s);
   void end(hipStream_t s);
   void collect();  // after the stream has been synchronised
   void reset();
   bool on = false;
+  std::string filter;    // non-empty: only this tag is timed
+  int sample_every = 1;  // time every n-th launch of a tag (keeps the event overhead out of the timed region)
   std::vector<std::pair<std::string, ProfStat>> stats() const;
 
  private:
@@ -40,13 +44,14 @@ class Profiler {
   size_t used_ = 0;
   std::vector<std::string> tags_;
   std::vector<ProfStat> stats_;
+  std::vector<int64_t> seen_;
 };
 extern thread_local Profiler* g_prof;
 struct ProfScope {  // RAII bracket used inside the launchers
   hipStream_t s;
   bool active;
   ProfScope(const char* tag, double flops, double bytes, hipStream_t st) : s(st), active(g_prof && g_prof->on) {
-    if (active) g_prof->begin(tag, flops, bytes, s);
+    if (active) active = g_prof->begin(tag, flops, bytes, s);
   }
   ~ProfScope() {
     if (active) g_prof->end(s);

@@ -138,7 +138,7 @@ class Model : public ModelBase {
   float* upload_f32(const std::vector<float>& v);
   std::vector<float> to_host(const std::string& name);
   T* pack_rows(T* dst, int dst_row0, const std::string& name, int rows, int cols, int kpad);
-  Lin<T> pack_linear(const std::string& wname, const std::string& bname, int n, int k);
+  Lin<T> pack_linear(const std::string& wname, const std::string& bname, int n, int k, int kalign = 8);
   LinF pack_linear_f32(const std::string& wname, const std::string& bname, int n, int k);
   Affine affine(const std::string& prefix, bool bias = true);
   template <typename U>
@@ -308,10 +308,10 @@ T* Model<T>::pack_rows(T* dst, int dst_row0, const std::string& name, int rows, 
   return dst;
 }
 template <typename T>
-Lin<T> Model<T>::pack_linear(const std::string& wname, const std::string& bname, int n, int k) {
+Lin<T> Model<T>::pack_linear(const std::string& wname, const std::string& bname, int n, int k, int kalign) {
   Lin<T> l;
   l.n = n;
-  l.k = round_up(k, 8);
+  l.k = round_up(k, kalign);
   l.w = talloc<T>((size_t)n * l.k);
   if (l.k != k) HIP_TRY(hipMemset(l.w, 0, (size_t)n * l.k * sizeof(T)));
   pack_rows(l.w, 0, wname, n, k, l.k);
@@ -355,7 +355,7 @@ void Model<T>::finalize() {
     const int Dc = c.clip_dim, g = c.clip_image / c.clip_patch;
     clip_n_ = g * g;
     const int K = 3 * c.clip_patch * c.clip_patch;
-    clip_patch_ = pack_linear(p + "embeddings.patch_embedding.weight", "", Dc, K);
+    clip_patch_ = pack_linear(p + "embeddings.patch_embedding.weight", "", Dc, K, 64);  // 588 -> 640 (zero weights)
     clip_kp_ = clip_patch_.k;
     clip_cls_ = own_f32(p + "embeddings.class_embedding");
     clip_pos_ = own_f32(p + "embeddings.position_embedding.weight");
@@ -493,6 +493,7 @@ void Model<T>::finalize() {
   {
     const std::string p = std::string(SAM_P) + "image_encoder.";
     const int D = c.sam_dim, g = c.sam_img / c.sam_patch, ws = c.sam_window, hd = D / c.sam_heads, C = c.sam_out_chans;
+    const int nh_sam = c.sam_heads;
     sam_g_ = g;
     sam_nw_ = cdiv(g, ws);
     sam_wrows_ = sam_nw_ * sam_nw_ * ws * ws;
@@ -517,12 +518,15 @@ void Model<T>::finalize() {
       if (raw(bp + "attn.rel_pos_w").numel() != (int64_t)(2 * sz - 1) * hd)
         throw std::runtime_error("rel_pos_w table of " + bp + " has the wrong shape");
       const int Np = 2 * sz;
+      // K padded with ZERO weights to a multiple of 64 (the fast GEMM's K tile): the A operand
+      // then reads a few finite q/k values past this head's 80 columns, multiplied by zero.
+      const int kp = round_up(hd, 64) <= 3 * D - (nh_sam - 1) * hd ? round_up(hd, 64) : hd;
       L.rel.n = 2 * Np;
-      L.rel.k = hd;
-      L.rel.w = talloc<T>((size_t)2 * Np * hd);
-      HIP_TRY(hipMemset(L.rel.w, 0, (size_t)2 * Np * hd * sizeof(T)));
-      pack_rows(L.rel.w, 0, bp + "attn.rel_pos_h", 2 * sz - 1, hd, hd);
-      pack_rows(L.rel.w, Np, bp + "attn.rel_pos_w", 2 * sz - 1, hd, hd);
+      L.rel.k = kp;
+      L.rel.w = talloc<T>((size_t)2 * Np * kp);
+      HIP_TRY(hipMemset(L.rel.w, 0, (size_t)2 * Np * kp * sizeof(T)));
+      pack_rows(L.rel.w, 0, bp + "attn.rel_pos_h", 2 * sz - 1, hd, kp);
+      pack_rows(L.rel.w, Np, bp + "attn.rel_pos_w", 2 * sz - 1, hd, kp);
     }
     neck0_ = pack_linear(p + "neck.0.weight", "", C, D);
     neck1_ = affine(p + "neck.1");
@@ -682,7 +686,11 @@ void Model<T>::finalize() {
     m_masks_ = talloc<float>((size_t)n * nt * 16 * NK);
     m_iou_ = talloc<float>((size_t)n * nt);
   }
-  HIP_TRY(hipStreamCreateWithFlags(&s2_, hipStreamNonBlocking));
+  {
+    int least = 0, greatest = 0;  // the side stream yields to the caller's stream
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    HIP_TRY(hipStreamCreateWithPriority(&s2_, hipStreamNonBlocking, least));
+  }
   HIP_TRY(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&ev_sam_, hipEventDisableTiming));
   HIP_TRY(hipDeviceSynchronize());
@@ -909,8 +917,8 @@ void Model<T>::sam_encoder(hipStream_t s, const float* images, int B, float* out
     // (batch = heads, A = the q columns of the fused qkv buffer); the attention kernel applies the shift.
     auto rel_gemm = [&](int rows) {
       GemmArgs r;
-      r.A = s_qkv_; r.lda = 3 * D; r.sA = hd; r.W = L.rel.w; r.ldw = hd; r.sW = 0;
-      r.C = s_relh_; r.ldc = L.rel.n; r.sC = (int64_t)rows * L.rel.n; r.M = rows; r.N = L.rel.n; r.K = hd;
+      r.A = s_qkv_; r.lda = 3 * D; r.sA = hd; r.W = L.rel.w; r.ldw = L.rel.k; r.sW = 0;
+      r.C = s_relh_; r.ldc = L.rel.n; r.sC = (int64_t)rows * L.rel.n; r.M = rows; r.N = L.rel.n; r.K = L.rel.k;
       r.c_f32 = 1; r.batch = nh;
       launch_gemm<T>(r, s);
       a.rel_p = s_relh_; a.rel_ld = L.rel.n; a.rel_hs = (int64_t)rows * L.rel.n;
@@ -1207,13 +1215,15 @@ void Model<T>::generate(hipStream_t s, const float* clip_images, const float* sa
   const int H = c.llm_dim, S = c.llm_max_seq, n_img = clip_n_;
   const bool keep_q = c.rephrase_weight > 0.f;
 
-  fork_sam(s, sam_images, B);
   clip_tower(s, clip_images, B);
   std::vector<int> slen, img_pos;
   const int Sp = splice_inputs(s, input_ids, lens, B, Lmax, extra_embeds, extra_slots, n_extra, slen, img_pos);
   for (int b = 0; b < B; ++b)
     if (slen[b] + max_new_tokens > S) throw std::runtime_error("prompt + max_new_tokens exceeds llm_max_seq");
   llm_prefill(s, B, Sp, slen_dev_, keep_q);
+  // Fork the SAM encoder only now: CLIP + prefill are MFMA-bound themselves, the decode loop that
+  // follows is HBM-bound and leaves the matrix cores to the encoder on the second stream.
+  fork_sam(s, sam_images, B);
   // first token: logits of the last prompt row of every sequence
   {
     std::vector<int> bb(B), pp(B);

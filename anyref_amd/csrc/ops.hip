@@ -12,15 +12,18 @@ Profiler::~Profiler() {
     (void)hipEventDestroy(p.second);
   }
 }
-void Profiler::begin(const char* tag, double flops, double bytes, hipStream_t s) {
+bool Profiler::begin(const char* tag, double flops, double bytes, hipStream_t s) {
+  if (!filter.empty() && filter != tag) return false;
   int t = -1;
   for (size_t i = 0; i < tags_.size(); ++i)
     if (tags_[i] == tag) t = (int)i;
   if (t < 0) {
     tags_.push_back(tag);
     stats_.push_back(ProfStat());
+    seen_.push_back(0);
     t = (int)tags_.size() - 1;
   }
+  if (sample_every > 1 && (seen_[t]++ % sample_every) != 0) return false;
   if (used_ == pool_.size()) {
     hipEvent_t a, b;
     HIP_TRY(hipEventCreate(&a));
@@ -31,6 +34,7 @@ void Profiler::begin(const char* tag, double flops, double bytes, hipStream_t s)
   ++used_;
   HIP_TRY(hipEventRecord(r.a, s));
   recs_.push_back(r);
+  return true;
 }
 void Profiler::end(hipStream_t s) { HIP_TRY(hipEventRecord(recs_.back().b, s)); }
 void Profiler::collect() {
@@ -50,6 +54,7 @@ void Profiler::reset() {
   recs_.clear();
   used_ = 0;
   for (auto& s : stats_) s = ProfStat();
+  for (auto& n : seen_) n = 0;
 }
 std::vector<std::pair<std::string, ProfStat>> Profiler::stats() const {
   std::vector<std::pair<std::string, ProfStat>> v;
@@ -103,9 +108,90 @@ __global__ __launch_bounds__(256) void norm_kernel(NormArgs a) {
   }
 }
 
+// Wide rows (D >= 1024, 16-byte aligned): one 256-thread workgroup per row, float4 loads, the row
+// stays in registers between the statistics and the normalise pass.
+template <typename T, int NV>  // NV float4 per thread: D <= 256*4*NV
+__global__ __launch_bounds__(256) void norm_wide_kernel(NormArgs a) {
+  const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int dm = a.row_map ? a.row_map[m] : m;
+  if (dm < 0) return;
+  __shared__ float red[8];
+  const float4v* x4 = reinterpret_cast<const float4v*>(a.x + (int64_t)m * a.ldx);
+  const int n4 = a.D / 4;
+  float4v v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int j = tid + i * 256;
+    v[i] = j < n4 ? x4[j] : float4v{0.f, 0.f, 0.f, 0.f};
+    s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+  }
+  float mean = 0.f;
+  if (!a.rms) {
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    mean = (red[0] + red[1] + red[2] + red[3]) / (float)a.D;
+  }
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int j = tid + i * 256;
+    if (j < n4) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float c = v[i][e] - mean;
+        ss += c * c;
+      }
+    }
+  }
+  ss = wave_sum(ss);
+  if (lane == 0) red[4 + wave] = ss;
+  __syncthreads();
+  const float var = (red[4] + red[5] + red[6] + red[7]) / (float)a.D;
+  const float inv = a.rms ? rsqrtf(var + a.eps) : 1.f / sqrtf(var + a.eps);
+  const float4v* g4 = reinterpret_cast<const float4v*>(a.gain);
+  const float4v* b4 = reinterpret_cast<const float4v*>(a.bias);
+  float* yf = reinterpret_cast<float*>(a.y) + (int64_t)dm * a.ldy;
+  T* yt = reinterpret_cast<T*>(a.y) + (int64_t)dm * a.ldy;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int j = tid + i * 256;
+    if (j >= n4) continue;
+    const float4v g = g4[j];
+    float4v o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * inv * g[e];
+    if (a.bias) {
+      const float4v bb = b4[j];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] += bb[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = apply_act(o[e], a.act);
+    if (a.y_f32) {
+      *reinterpret_cast<float4v*>(yf + 4 * j) = o;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) yt[4 * j + e] = from_f32<T>(o[e]);
+    }
+  }
+}
+
 template <typename T>
 void launch_norm(const NormArgs& a, hipStream_t s) {
   if (a.M <= 0) return;
+  if (a.D >= 1024 && a.D % 4 == 0 && a.ldx % 4 == 0 && a.ldy % 4 == 0 && !((uintptr_t)a.x & 15) &&
+      !((uintptr_t)a.y & 15) && !((uintptr_t)a.gain & 15) && !((uintptr_t)a.bias & 15) && a.D <= 8192) {
+    dim3 g(a.M), b(256);
+    if (a.D <= 2048)
+      hipLaunchKernelGGL((norm_wide_kernel<T, 2>), g, b, 0, s, a);
+    else if (a.D <= 4096)
+      hipLaunchKernelGGL((norm_wide_kernel<T, 4>), g, b, 0, s, a);
+    else
+      hipLaunchKernelGGL((norm_wide_kernel<T, 8>), g, b, 0, s, a);
+    return;
+  }
   dim3 grid(cdiv(a.M, 4)), block(256);
   const int nv = cdiv(a.D, 64);
   if (nv <= 1)

@@ -173,7 +173,9 @@ class AnyRefForCausalLM:
         self._check(self.lib.anyref_set_seg_range(self.h, lo, hi), "set_seg_range")
 
     # ---- per-kernel timing for bench.py ------------------------------------------------------
-    def profile_enable(self, on: bool):
+    def profile_enable(self, on: bool, only_tag: Optional[str] = None, sample_every: int = 1):
+        self._check(self.lib.anyref_profile_config(self.h, only_tag.encode() if only_tag else None, sample_every),
+                    "profile_config")
         self._check(self.lib.anyref_profile_enable(self.h, int(on)), "profile_enable")
 
     def profile_read(self):

@@ -159,6 +159,9 @@ int anyref_set_seg_range(anyref_handle* h, int lo, int hi);
  * bytes (returns -1 past the last tag).
  */
 int anyref_profile_enable(anyref_handle* h, int on);
+/* Restrict timing to one tag (NULL = all) and to every `sample_every`-th launch of a tag, so the
+ * event pairs do not perturb the timed region they measure. */
+int anyref_profile_config(anyref_handle* h, const char* only_tag, int sample_every);
 int anyref_profile_collect(anyref_handle* h);
 int anyref_profile_read(anyref_handle* h, int idx, char* name, int cap, double* ms, int64_t* count,
                         double* flops, double* bytes);

@@ -58,7 +58,7 @@ def close(got, ref, tol):
 
 @pytest.mark.parametrize("ty", [0, 1])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (257, 192, 192), (320, 384, 1032), (6, 256, 256), (1000, 64, 72),
-                                   (70, 130, 24)])
+                                   (70, 130, 24), (4900, 200, 1280), (320, 640, 4096), (64, 128, 128)])
 @pytest.mark.parametrize("act", [0, 1, 2, 3, 4])
 def test_gemm(lib, ty, M, N, K, act):
     g = torch.Generator().manual_seed(M * 7 + N * 3 + K + act)
