@@ -11,6 +11,7 @@
 // loads (issue tile t+1 before computing tile t, write to LDS after the barrier: T14 split).
 #include <cstdlib>
 #include <stdexcept>
+#include <utility>
 #include "kernels.h"
 
 namespace anyref {
@@ -42,41 +43,84 @@ struct Mma<float> {
 };
 
 // Shared epilogue: bias, activation, residual, row map, typed store.
+// The main loop issues mfma(W-fragment, A-fragment), i.e. it accumulates the TRANSPOSED 16x16 tile:
+// lane l then holds C[m = tile_m + (l & 15)][n = tile_n + 4 * (l >> 4) + r], r = 0..3 -- four
+// CONSECUTIVE columns of one output row, stored as one 8-byte (bf16) / 16-byte (f32) vector.  With the
+// natural orientation a lane holds four rows of one column and the tile leaves as 2-4-byte scalars:
+// 4x the store instructions, and the store tail (issue-bound, cf. guide T21) cost ~30 us of an 84 us
+// 4096x3840x1280 GEMM.
+// compile-time loop: the callable receives std::integral_constant indices
+template <int... Is, typename F>
+__device__ __forceinline__ void static_for(std::integer_sequence<int, Is...>, F&& f) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+
+template <typename T>
+__device__ __forceinline__ void epi_store4(const GemmArgs& a, const float* bias, const float* resid, float* Cf, T* Ct,
+                                           bool vec, int dm, int n, float v0, float v1, float v2, float v3) {
+  if (vec) {  // N % 4 == 0: the four columns are all valid, rows are 16-byte aligned
+    float4v v = float4v{v0, v1, v2, v3};
+    if (bias) v += *reinterpret_cast<const float4v*>(bias + n);
+    v = float4v{apply_act(v[0], a.act), apply_act(v[1], a.act), apply_act(v[2], a.act), apply_act(v[3], a.act)};
+    if (resid) v += *reinterpret_cast<const float4v*>(resid + (int64_t)dm * a.ldr + n);
+    if (a.c_f32) {
+      *reinterpret_cast<float4v*>(Cf + (int64_t)dm * a.ldc + n) = v;
+    } else if constexpr (sizeof(T) == 2) {
+      const uint32_t lo = (uint32_t)f2bf(v[0]).x | ((uint32_t)f2bf(v[1]).x << 16);
+      const uint32_t hi = (uint32_t)f2bf(v[2]).x | ((uint32_t)f2bf(v[3]).x << 16);
+      *reinterpret_cast<uint2*>(Ct + (int64_t)dm * a.ldc + n) = make_uint2(lo, hi);
+    } else {
+      *reinterpret_cast<float4v*>(Ct + (int64_t)dm * a.ldc + n) = v;
+    }
+    return;
+  }
+  // scalar tail path (N not a multiple of 4 / unaligned)
+  const float vs0 = v0, vs1 = v1, vs2 = v2, vs3 = v3;
+#define ANYREF_PUT(r, x0)                                         \
+  if (n + r < a.N) {                                              \
+    float x = x0;                                                 \
+    if (bias) x += bias[n + r];                                   \
+    x = apply_act(x, a.act);                                      \
+    if (resid) x += resid[(int64_t)dm * a.ldr + n + r];           \
+    if (a.c_f32)                                                  \
+      Cf[(int64_t)dm * a.ldc + n + r] = x;                        \
+    else                                                          \
+      Ct[(int64_t)dm * a.ldc + n + r] = from_f32<T>(x);           \
+  }
+  ANYREF_PUT(0, vs0)
+  ANYREF_PUT(1, vs1)
+  ANYREF_PUT(2, vs2)
+  ANYREF_PUT(3, vs3)
+#undef ANYREF_PUT
+}
+
 template <typename T, int BM, int BN>
-__device__ inline void gemm_epilogue(const GemmArgs& a, float4v (&acc)[BM / 32][BN / 32], int m0, int n0, int z,
-                                     int lane, int wr, int wc) {
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, float4v (&acc)[BM / 32][BN / 32], int m0, int n0, int z,
+                                              int lane, int wr, int wc) {
   constexpr int MI = BM / 32, NI = BN / 32;
   const float* bias = a.bias ? a.bias + (int64_t)z * a.sBias : nullptr;
   const float* resid = a.resid ? a.resid + (int64_t)z * a.sR : nullptr;
   float* Cf = reinterpret_cast<float*>(a.C) + (int64_t)z * a.sC;
   T* Ct = reinterpret_cast<T*>(a.C) + (int64_t)z * a.sC;
+  const bool vec = a.vec_ok != 0;
+  // NB: every acc index must stay a compile-time constant (full unroll, no `continue`): a runtime-indexed
+  // accumulator array is demoted to scratch memory for the WHOLE kernel (guide rule 20; measured 3x slower).
+  int dms[MI];
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int m = m0 + wr * (BM / 2) + i * 16 + (lane >> 4) * 4 + r;
-      if (m >= a.M) continue;
-      const int dm = a.row_map ? a.row_map[m] : m;
-      if (dm < 0) continue;
-#pragma unroll
-      for (int j = 0; j < NI; ++j) {
-        const int n = n0 + wc * (BN / 2) + j * 16 + (lane & 15);
-        if (n >= a.N) continue;
-        float v = acc[i][j][r] * a.alpha;
-        if (bias) v += bias[n];
-        v = apply_act(v, a.act);
-        if (resid) v += resid[(int64_t)dm * a.ldr + n];
-        if (a.c_f32)
-          Cf[(int64_t)dm * a.ldc + n] = v;
-        else
-          Ct[(int64_t)dm * a.ldc + n] = from_f32<T>(v);
-      }
-    }
+    const int m = m0 + wr * (BM / 2) + i * 16 + (lane & 15);
+    dms[i] = m < a.M ? (a.row_map ? a.row_map[m] : m) : -1;
   }
+  static_for(std::make_integer_sequence<int, MI * NI>{}, [&](auto ij) {
+    constexpr int i = decltype(ij)::value / NI, j = decltype(ij)::value % NI;
+    const int n = n0 + wc * (BN / 2) + j * 16 + 4 * (lane >> 4);
+    const float4v v = acc[i][j] * a.alpha;
+    if (dms[i] >= 0 && n < a.N) epi_store4<T>(a, bias, resid, Cf, Ct, vec, dms[i], n, v[0], v[1], v[2], v[3]);
+  });
 }
 
 template <typename T, int BM, int BN, int BK>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
+__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a) {  // 2 waves/SIMD: 256-register budget
   using M_ = Mma<T>;
   constexpr int VEC = M_::VEC, KS = M_::KS;
   constexpr int LD = BK + VEC;  // +16 B row pad
@@ -89,7 +133,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  // 1-D grid, XCD-aware bijective remap (T1), then M-fastest tile order: the workgroups that share
+  // a weight panel are neighbours on one XCD's L2
+  const int tiles_m = cdiv(a.M, BM), tiles_n = cdiv(a.N, BN), nwg = tiles_m * tiles_n;
+  int id = blockIdx.x;
+  if (a.order & 1) {
+    const int q = nwg / 8, r = nwg % 8, xcd = id % 8;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + id / 8;
+  }
+  const int m0 = ((a.order & 2) ? id % tiles_m : id / tiles_n) * BM;
+  const int n0 = ((a.order & 2) ? id / tiles_m : id % tiles_n) * BN;
   const int z = blockIdx.z;
   const T* __restrict__ A = reinterpret_cast<const T*>(a.A) + (int64_t)z * a.sA;
   const T* __restrict__ W = reinterpret_cast<const T*>(a.W) + (int64_t)z * a.sW;
@@ -149,7 +202,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < NI; ++j) acc[i][j] = M_::mma(af[i], bf[j], acc[i][j]);
+        for (int j = 0; j < NI; ++j) acc[i][j] = M_::mma(bf[j], af[i], acc[i][j]);  // C^T tile: see gemm_epilogue
     }
     __syncthreads();
   }
@@ -157,143 +210,47 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
   gemm_epilogue<T, BM, BN>(a, acc, m0, n0, z, lane, wr, wc);
 }
 
-// ---------------------------------------------------------------------------------------------
-// bf16 main GEMM: BM x 128 x 64 tile, operands staged HBM -> LDS by global_load_lds (16 B/lane,
-// no VGPR round trip), two LDS buffers, one barrier per K tile (guide §5.5 "minimum 2-phase").
-// LDS rows are 128 B; a wave-instruction fills 8 rows linearly, so the bank-conflict swizzle
-// (16-B chunk index ^ (row & 7)) is applied to the per-lane SOURCE address and again on the
-// fragment read (guide rule 21).  Rows past M / N are clamped to the last valid row (their
-// results are never stored); K must be a multiple of 64 here (launcher falls back otherwise).
-// Tiles are walked M-fastest inside an XCD-contiguous chunk of the grid so that the blocks that
-// share a weight panel hit the same L2 (T1, bijective remap).
-// ---------------------------------------------------------------------------------------------
-template <int BM>
-__global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs a, int tiles_m, int tiles_n) {
-  constexpr int BN = 128, BK = 64;
-  constexpr int MI = BM / 32, NI = BN / 32;
-  constexpr int A_INST = BM / 8, B_INST = BN / 8, PER_WAVE = (A_INST + B_INST) / 4;
-  constexpr int TILE_A = BM * BK, TILE_B = BN * BK;  // elements
-  __shared__ __attribute__((aligned(16))) bf16 lds[2 * (TILE_A + TILE_B)];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
-  // XCD-aware, bijective block remap; then M-fastest tile order
-  const int nwg = tiles_m * tiles_n;
-  int id = blockIdx.x;
-  {
-    const int q = nwg / 8, r = nwg % 8, xcd = id % 8;
-    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + id / 8;
-  }
-  const int pm = id % tiles_m, pn = id / tiles_m;
-  const int m0 = pm * BM, n0 = pn * BN;
-  const int z = blockIdx.z;
-  const bf16* __restrict__ A = reinterpret_cast<const bf16*>(a.A) + (int64_t)z * a.sA;
-  const bf16* __restrict__ W = reinterpret_cast<const bf16*>(a.W) + (int64_t)z * a.sW;
-
-  // per-lane source pointers of this wave's staging instructions (tile 0), advanced by BK per tile
-  const bf16* src[PER_WAVE];
-  int dst[PER_WAVE];  // LDS element offset of the instruction's 1 KiB destination within a buffer
-#pragma unroll
-  for (int i = 0; i < PER_WAVE; ++i) {
-    const int inst = wave + 4 * i;  // A instructions first, then B
-    const bool isA = inst < A_INST;
-    const int li = isA ? inst : inst - A_INST;
-    const int r = li * 8 + (lane >> 3), pc = lane & 7, lc = pc ^ (r & 7);
-    if (isA) {
-      int gm = m0 + r;
-      gm = gm < a.M ? gm : a.M - 1;
-      src[i] = A + (int64_t)gm * a.lda + lc * 8;
-      dst[i] = li * 512;
-    } else {
-      int gn = n0 + r;
-      gn = gn < a.N ? gn : a.N - 1;
-      src[i] = W + (int64_t)gn * a.ldw + lc * 8;
-      dst[i] = TILE_A + li * 512;
-    }
-  }
-  auto stage = [&](int buf) {
-    bf16* base = lds + buf * (TILE_A + TILE_B);
-#pragma unroll
-    for (int i = 0; i < PER_WAVE; ++i) {
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src[i],
-                                       (__attribute__((address_space(3))) void*)(base + dst[i]), 16, 0, 0);
-      src[i] += BK;
-    }
-  };
-
-  float4v acc[MI][NI];
-#pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int j = 0; j < NI; ++j) acc[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
-
-  const int nt = a.K / BK;
-  stage(0);
-  __syncthreads();
-  for (int t = 0; t < nt; ++t) {
-    const int buf = t & 1;
-    if (t + 1 < nt) stage(buf ^ 1);
-    const bf16* As = lds + buf * (TILE_A + TILE_B);
-    const bf16* Bs = As + TILE_A;
-#pragma unroll
-    for (int ks = 0; ks < BK / 32; ++ks) {
-      const int pc = ((ks * 4 + (lane >> 4)) ^ (lane & 7)) * 8;  // swizzled 16-B chunk of this lane
-      short8 af[MI], bfr[NI];
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-        af[i] = *reinterpret_cast<const short8*>(As + (wr * (BM / 2) + i * 16 + (lane & 15)) * BK + pc);
-#pragma unroll
-      for (int j = 0; j < NI; ++j)
-        bfr[j] = *reinterpret_cast<const short8*>(Bs + (wc * (BN / 2) + j * 16 + (lane & 15)) * BK + pc);
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-    }
-    __syncthreads();
-  }
-  gemm_epilogue<bf16, BM, BN>(a, acc, m0, n0, z, lane, wr, wc);
-}
-
-static bool launch_gemm_glds(const GemmArgs& a, hipStream_t s) {
-  // measured on MI355X (scratch/bench_gemm.py): the glds kernel wins when at least one full wave of
-  // 128x128 tiles exists; below that the register-staged kernel's smaller tiles fill the chip better
-  if (a.K % 64 || a.K < 64) return false;
-  const int tn = cdiv(a.N, 128);
-  const bool bm128 = true;
-  if ((int64_t)cdiv(a.M, 128) * tn * a.batch < 256) return false;
-  const int tm = cdiv(a.M, 128);
-  const double flops = 2.0 * a.M * a.N * (double)a.K * a.batch;
-  const double bytes = ((double)a.M * a.K + (double)a.N * a.K) * 2 * a.batch + (double)a.M * a.N * (a.c_f32 ? 4 : 2) * a.batch;
-  ProfScope prof(bm128 ? "gemm_bf16_glds_128x128" : "gemm_bf16_glds_64x128", flops, bytes, s);
-  dim3 grid(tm * tn, 1, a.batch);
-  if (bm128)
-    hipLaunchKernelGGL((gemm_glds_kernel<128>), grid, dim3(256), 0, s, a, tm, tn);
-  else
-    hipLaunchKernelGGL((gemm_glds_kernel<64>), grid, dim3(256), 0, s, a, tm, tn);
-  return true;
-}
-
 template <typename T>
-void launch_gemm(const GemmArgs& a, hipStream_t s) {
+void launch_gemm(const GemmArgs& a_in, hipStream_t s) {
+  GemmArgs a = a_in;
   constexpr int VEC = Mma<T>::VEC;
   constexpr int BK = sizeof(T) == 2 ? 64 : 16;
   if (a.M <= 0 || a.N <= 0) return;
   if (a.K % VEC || a.lda % VEC || a.ldw % VEC || ((uintptr_t)a.A & 15) || ((uintptr_t)a.W & 15) ||
       (a.sA % VEC) || (a.sW % VEC))
     throw std::runtime_error("gemm: K/lda/ldw must be multiples of 16 bytes and operands 16-byte aligned");
-  static const bool force_old = getenv("ANYREF_GEMM_OLD") != nullptr;  // A/B switch for microbenchmarks
-  if (sizeof(T) == 2 && a.M >= 48 && !force_old && launch_gemm_glds(a, s)) return;
-  // tile choice: fewest padded rows first, then enough workgroups to cover the 256 CUs
-  const int waste128 = cdiv(a.M, 128) * 128 - a.M, waste64 = cdiv(a.M, 64) * 64 - a.M;
-  bool bm128 = waste128 <= waste64 + 16;
-  int bn = 128;
-  auto blocks = [&](int bm, int bnn) { return (int64_t)cdiv(a.M, bm) * cdiv(a.N, bnn) * a.batch; };
-  if (blocks(bm128 ? 128 : 64, 128) < 256) {
-    if (bm128 && blocks(64, 128) >= 2 * blocks(128, 128)) bm128 = false;
-    if (blocks(bm128 ? 128 : 64, 128) < 256) bn = 64;
+  // Tile choice, from measurements on MI355X (scratch/bench_gemm.py, all four variants per shape):
+  // 128x128 once there are >= 2 tiles per CU; 64x128 for mid-size N (more, smaller tiles fill the
+  // chip) and for skinny-M / wide-N weight-streaming shapes; 64x64 when even that leaves CUs idle.
+  const int64_t t128 = (int64_t)cdiv(a.M, 128) * cdiv(a.N, 128) * a.batch;
+  const int64_t t64x128 = (int64_t)cdiv(a.M, 64) * cdiv(a.N, 128) * a.batch;
+  bool bm128;
+  int bn;
+  if (a.M <= 512) {
+    bm128 = false;
+    bn = t64x128 >= 384 ? 128 : 64;
+  } else if (t128 >= 512) {
+    bm128 = true;
+    bn = 128;
+  } else {
+    bm128 = false;
+    bn = t64x128 >= 256 ? 128 : 64;
+  }
+  if (const char* fv = getenv("ANYREF_GEMM_TILE")) {  // microbenchmark knob: force a tile variant
+    const int v = atoi(fv);
+    bm128 = v & 2;
+    bn = (v & 1) ? 128 : 64;
   }
   dim3 block(256);
+  static const int order_env = getenv("ANYREF_GEMM_ORDER") ? atoi(getenv("ANYREF_GEMM_ORDER")) : 3;
+  a.order = order_env;
+  {
+    const int ov = a.c_f32 ? 4 : (int)sizeof(T);  // output element bytes
+    const bool al = a.N % 4 == 0 && a.ldc % 4 == 0 && a.sC % 4 == 0 && !((uintptr_t)a.C & 15) &&
+                    (!a.resid || (a.ldr % 4 == 0 && a.sR % 4 == 0 && !((uintptr_t)a.resid & 15))) &&
+                    (!a.bias || (a.sBias % 4 == 0 && !((uintptr_t)a.bias & 15)));
+    a.vec_ok = al && (ov == 4 || ov == 2) ? 1 : 0;
+  }
   const double flops = 2.0 * a.M * a.N * (double)a.K * a.batch;
   const double bytes = ((double)a.M * a.K + (double)a.N * a.K) * sizeof(T) * a.batch +
                        (double)a.M * a.N * (a.c_f32 ? 4 : sizeof(T)) * a.batch;
@@ -303,16 +260,16 @@ void launch_gemm(const GemmArgs& a, hipStream_t s) {
                                             : (bn == 128 ? "gemm_f32_64x128" : "gemm_f32_64x64"));
   ProfScope prof(tag, flops, bytes, s);
   if (bm128 && bn == 128) {
-    dim3 grid(cdiv(a.N, 128), cdiv(a.M, 128), a.batch);
+    dim3 grid(cdiv(a.N, 128) * cdiv(a.M, 128), 1, a.batch);
     hipLaunchKernelGGL((gemm_kernel<T, 128, 128, BK>), grid, block, 0, s, a);
   } else if (bm128) {
-    dim3 grid(cdiv(a.N, 64), cdiv(a.M, 128), a.batch);
+    dim3 grid(cdiv(a.N, 64) * cdiv(a.M, 128), 1, a.batch);
     hipLaunchKernelGGL((gemm_kernel<T, 128, 64, BK>), grid, block, 0, s, a);
   } else if (bn == 128) {
-    dim3 grid(cdiv(a.N, 128), cdiv(a.M, 64), a.batch);
+    dim3 grid(cdiv(a.N, 128) * cdiv(a.M, 64), 1, a.batch);
     hipLaunchKernelGGL((gemm_kernel<T, 64, 128, BK>), grid, block, 0, s, a);
   } else {
-    dim3 grid(cdiv(a.N, 64), cdiv(a.M, 64), a.batch);
+    dim3 grid(cdiv(a.N, 64) * cdiv(a.M, 64), 1, a.batch);
     hipLaunchKernelGGL((gemm_kernel<T, 64, 64, BK>), grid, block, 0, s, a);
   }
 }

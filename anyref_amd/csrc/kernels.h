@@ -71,6 +71,8 @@ struct GemmArgs {
   int act = ACT_NONE;
   int c_f32 = 0;  // 1: C is f32, 0: C is T
   float alpha = 1.f;
+  int order = 3;   // bit 0: XCD-chunked block remap, bit 1: M-fastest tile order
+  int vec_ok = 0;  // set by the launcher: N / strides / bases allow 4-wide vector epilogue accesses
   // optional batching over blockIdx.z (element strides)
   int batch = 1;
   int64_t sA = 0, sW = 0, sC = 0, sR = 0, sBias = 0;

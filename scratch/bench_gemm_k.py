@@ -1,0 +1,18 @@
+import ctypes as C, torch, sys, os
+sys.path.insert(0, '.')
+from anyref_amd import _lib
+lib = _lib.load()
+P = lambda t: C.c_void_p(t.data_ptr())
+for (M, N) in [(4096, 3840), (2048, 2048), (4096, 1280)]:
+  for K in [64, 128, 256, 512, 1280, 2560, 5120]:
+    A = torch.randn(M, K, device='cuda').bfloat16(); W = (torch.randn(N, K, device='cuda') * 0.05).bfloat16()
+    Cc = torch.empty(M, N, device='cuda', dtype=torch.bfloat16)
+    for _ in range(3): lib.anyref_op_gemm(1, None, P(A), P(W), None, P(Cc), None, None, M, N, K, 0, 0)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = 30
+    e0.record()
+    for _ in range(n): lib.anyref_op_gemm(1, None, P(A), P(W), None, P(Cc), None, None, M, N, K, 0, 0)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    print(f"{M:6d} {N:6d} {K:6d}  {ms*1e3:9.1f} us  {2*M*N*K/ms/1e9:8.1f} TF")
