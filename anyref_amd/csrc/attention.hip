@@ -9,6 +9,7 @@
 // Workgroup = 4 waves = 64 query rows (16 per wave, Q fragments live in registers); K/V tiles of
 // BKV keys go through LDS (V transposed for the bf16 B-operand), S = QK^T and O += PV on MFMA,
 // softmax statistics per row in registers (rows sit on 16-lane groups of the C layout).
+#include <cstdlib>
 #include <type_traits>
 
 #include "kernels.h"
@@ -55,15 +56,62 @@ struct AttnTile {
   static constexpr int BKV = sizeof(T) == 2 ? 64 : 32;
 };
 
-template <typename T, int HD>
+// ---- B-operand fragments of P.V from a ROW-major V tile --------------------------------------
+// f32: one scalar per lane (B[k = lane>>4][n = lane&15]).
+// bf16: the 8 k-values of a lane's column sit in 8 different rows; gfx950's ds_read_b64_tr_b16
+// (guide T10) transposes 4 rows x 16 columns per 16-lane group in the LDS read itself, so V is
+// staged with plain 16-byte row stores (no 2-byte transposing scatter).  Lane 4q+p of a group
+// supplies the address of row q, columns 4p..4p+3; lane i receives column i of the 4 rows.  Two
+// reads (rows +0 and +4) make one 8-element fragment.  Reads and their wait live in ONE asm
+// statement (guide §5.7 form (i)); EXEC is all ones here (only wave-uniform control flow above).
+typedef __attribute__((ext_vector_type(2))) uint32_t uint2v;
+
+template <int ROW4>  // byte offset of 4 rows
+__device__ inline void lds_tr_frag1(uint32_t addr, uint4v& f0) {
+  uint2v a0, b0;
+  asm volatile(
+      "ds_read_b64_tr_b16 %0, %2\n\t"
+      "ds_read_b64_tr_b16 %1, %2 offset:%3\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(a0), "=&v"(b0)
+      : "v"(addr), "i"(ROW4)
+      : "memory");
+  f0 = uint4v{a0[0], a0[1], b0[0], b0[1]};
+}
+template <int ROW4>
+__device__ inline void lds_tr_frag4(uint32_t addr, uint4v& f0, uint4v& f1, uint4v& f2, uint4v& f3) {
+  uint2v a0, b0, a1, b1, a2, b2, a3, b3;
+  asm volatile(
+      "ds_read_b64_tr_b16 %0, %8\n\t"
+      "ds_read_b64_tr_b16 %1, %8 offset:%9\n\t"
+      "ds_read_b64_tr_b16 %2, %8 offset:32\n\t"
+      "ds_read_b64_tr_b16 %3, %8 offset:%10\n\t"
+      "ds_read_b64_tr_b16 %4, %8 offset:64\n\t"
+      "ds_read_b64_tr_b16 %5, %8 offset:%11\n\t"
+      "ds_read_b64_tr_b16 %6, %8 offset:96\n\t"
+      "ds_read_b64_tr_b16 %7, %8 offset:%12\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(a0), "=&v"(b0), "=&v"(a1), "=&v"(b1), "=&v"(a2), "=&v"(b2), "=&v"(a3), "=&v"(b3)
+      : "v"(addr), "i"(ROW4), "i"(ROW4 + 32), "i"(ROW4 + 64), "i"(ROW4 + 96)
+      : "memory");
+  f0 = uint4v{a0[0], a0[1], b0[0], b0[1]};
+  f1 = uint4v{a1[0], a1[1], b1[0], b1[1]};
+  f2 = uint4v{a2[0], a2[1], b2[0], b2[1]};
+  f3 = uint4v{a3[0], a3[1], b3[0], b3[1]};
+}
+
+// Workgroup = 4 waves; every wave owns RB row-blocks of 16 queries (BQ = 64*RB queries per
+// workgroup).  Only RB = 1 is instantiated (see attn_launch).
+template <typename T, int HD, int RB>
 __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
   using M_ = AMma<T>;
   constexpr int KS = M_::KS, VEC = M_::VEC;
+  constexpr bool BF = sizeof(T) == 2;
   constexpr int BKV = AttnTile<T>::BKV;
+  constexpr int BQ = 64 * RB;
   constexpr int HDK = (HD + KS - 1) / KS * KS;  // QK^T contraction length (zero padded)
   constexpr int LDK = HDK + VEC;                // K tile row stride
-  constexpr bool VT = sizeof(T) == 2;           // bf16: V stored transposed [d][key]
-  constexpr int LDV = VT ? BKV + VEC : HD + VEC;
+  constexpr int LDV = HD + VEC;                 // V tile row stride (row-major [key][d])
   constexpr int LDP = BKV + VEC;
   constexpr int NB = BKV / 16;  // key blocks of one tile
   constexpr int DB = HD / 16;   // output d blocks
@@ -72,19 +120,19 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* Ks = reinterpret_cast<T*>(smem);
   T* Vs = Ks + BKV * LDK;
-  T* Ps = Vs + (VT ? HD * LDV : BKV * LDV);
+  T* Ps = Vs + BKV * LDV;
   float* relh_s = reinterpret_cast<float*>(Ps + 4 * 16 * LDP);
-  float* relw_s = relh_s + 64 * a.kh;
+  float* relw_s = relh_s + BQ * a.kh;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
+  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * BQ;
   const int kv_len = a.kv_len ? a.kv_len[b] : a.Sk;
   const int q_len = a.q_len ? a.q_len[b] : a.Sq;
   if (q0 >= q_len) return;  // uniform per workgroup
   const int pos0 = a.q_pos0 ? a.q_pos0[b] : 0;
   int kv_end = kv_len;
   if (a.causal) {
-    const int imax = (q0 + 64 < q_len ? q0 + 64 : q_len) - 1;
+    const int imax = (q0 + BQ < q_len ? q0 + BQ : q_len) - 1;
     if (pos0 + imax + 1 < kv_end) kv_end = pos0 + imax + 1;
   }
 
@@ -92,25 +140,27 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
   const T* Kb = reinterpret_cast<const T*>(a.K) + (int64_t)b * a.k_bs + (int64_t)h * a.k_hs;
   const T* Vb = reinterpret_cast<const T*>(a.V) + (int64_t)b * a.v_bs + (int64_t)h * a.v_hs;
 
-  // Q fragments (A operand): row = lane&15 of this wave's 16 rows
-  typename M_::Frag qf[HDK / KS];
-  {
-    const int qr = q0 + wave * 16 + (lane & 15);
+  // Q fragments (A operand) of this wave's RB row-blocks; row-block rb starts at local row wrow0 + 16*rb
+  const int wrow0 = wave * 16 * RB;
+  typename M_::Frag qf[RB][HDK / KS];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    const int qr = q0 + wrow0 + rb * 16 + (lane & 15);
     const bool ok = qr < q_len;
     const T* qrow = Qb + (int64_t)(ok ? qr : 0) * a.q_rs;
 #pragma unroll
-    for (int kk = 0; kk < HDK / KS; ++kk) qf[kk] = M_::glb(qrow, kk * KS, lane, ok, HD);
+    for (int kk = 0; kk < HDK / KS; ++kk) qf[rb][kk] = M_::glb(qrow, kk * KS, lane, ok, HD);
   }
   const bool has_rel = a.rel_h != nullptr || a.rel_p != nullptr;
   if (a.rel_p) {
     const float* P = a.rel_p + (int64_t)h * a.rel_hs + ((int64_t)b * a.Sq + q0) * a.rel_ld;
     const int np = a.rel_ld / 2;
-    for (int i = tid; i < 64 * a.kh; i += 256) {
+    for (int i = tid; i < BQ * a.kh; i += 256) {
       const int r = i / a.kh, c = i % a.kh;
       const int y = (q0 + r) / a.kw;
       relh_s[i] = q0 + r < q_len ? P[(int64_t)r * a.rel_ld + (y - c + a.kh - 1)] : 0.f;
     }
-    for (int i = tid; i < 64 * a.kw; i += 256) {
+    for (int i = tid; i < BQ * a.kw; i += 256) {
       const int r = i / a.kw, c = i % a.kw;
       const int x = (q0 + r) % a.kw;
       relw_s[i] = q0 + r < q_len ? P[(int64_t)r * a.rel_ld + np + (x - c + a.kw - 1)] : 0.f;
@@ -118,31 +168,33 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
   } else if (has_rel) {
     const float* rh = a.rel_h + ((int64_t)b * a.H + h) * a.Sq * a.kh;
     const float* rw = a.rel_w + ((int64_t)b * a.H + h) * a.Sq * a.kw;
-    for (int i = tid; i < 64 * a.kh; i += 256) {
+    for (int i = tid; i < BQ * a.kh; i += 256) {
       const int r = i / a.kh, c = i % a.kh;
       relh_s[i] = q0 + r < q_len ? rh[(int64_t)(q0 + r) * a.kh + c] : 0.f;
     }
-    for (int i = tid; i < 64 * a.kw; i += 256) {
+    for (int i = tid; i < BQ * a.kw; i += 256) {
       const int r = i / a.kw, c = i % a.kw;
       relw_s[i] = q0 + r < q_len ? rw[(int64_t)(q0 + r) * a.kw + c] : 0.f;
     }
   }
 
-  float m_run[4], l_run[4];
-  float4v o[DB];
+  float m_run[RB][4], l_run[RB][4];
+  float4v o[RB][DB];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    m_run[r] = -INFINITY;
-    l_run[r] = 0.f;
+  for (int rb = 0; rb < RB; ++rb) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      m_run[rb][r] = -INFINITY;
+      l_run[rb][r] = 0.f;
+    }
+#pragma unroll
+    for (int d = 0; d < DB; ++d) o[rb][d] = float4v{0.f, 0.f, 0.f, 0.f};
   }
-#pragma unroll
-  for (int d = 0; d < DB; ++d) o[d] = float4v{0.f, 0.f, 0.f, 0.f};
 
-  T* Pw = Ps + wave * 16 * LDP;
-  const int irow0 = wave * 16 + 4 * (lane >> 4);  // local q row of acc element r=0
+  T* Pw = Ps + wave * 16 * LDP;  // wave-private P staging (C layout -> A operand)
 
   for (int kt = 0; kt < kv_end; kt += BKV) {
-    // ---- stage K [BKV][HDK] and V ---------------------------------------------------------
+    // ---- stage K [BKV][HDK] and V [BKV][HD], both row-major, 16-byte vectors ------------------
     constexpr int KVEC = HDK / VEC;
     for (int v = tid; v < BKV * KVEC; v += 256) {
       const int row = v / KVEC, d = (v % KVEC) * VEC;
@@ -157,26 +209,10 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
       const int j = kt + row;
       uint4v val = uint4v{0, 0, 0, 0};
       if (j < kv_end) val = *reinterpret_cast<const uint4v*>(Vb + (int64_t)j * a.v_rs + d);
-      if constexpr (VT) {
-        const uint16_t* e = reinterpret_cast<const uint16_t*>(&val);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) reinterpret_cast<uint16_t*>(Vs)[(d + i) * LDV + row] = e[i];
-      } else {
-        *reinterpret_cast<uint4v*>(&Vs[row * LDV + d]) = val;
-      }
+      *reinterpret_cast<uint4v*>(&Vs[row * LDV + d]) = val;
     }
     __syncthreads();
 
-    // ---- S = Q K^T ----------------------------------------------------------------------------
-    float4v sc[NB];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-      sc[nb] = float4v{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int kk = 0; kk < HDK / KS; ++kk)
-        sc[nb] = M_::mma(qf[kk], M_::lds(&Ks[(nb * 16 + (lane & 15)) * LDK + kk * KS], lane), sc[nb]);
-    }
-    // ---- scale, bias, mask, online softmax ----------------------------------------------------
     int jh[NB], jw[NB];
     if (has_rel) {
 #pragma unroll
@@ -191,98 +227,159 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
       }
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int il = irow0 + r, i = q0 + il;
-      float mx = -INFINITY;
+    for (int rb = 0; rb < RB; ++rb) {
+      const int lrow0 = wrow0 + rb * 16;      // first local row of this row-block
+      if (q0 + lrow0 >= q_len) continue;      // wave-uniform: nothing to do for rows past the end
+      if (a.causal && kt > pos0 + q0 + lrow0 + 15) continue;  // tile entirely in the future of these rows
+      // ---- S = Q K^T ------------------------------------------------------------------------
+      float4v sc[NB];
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
-        const int j = kt + nb * 16 + (lane & 15);
-        float s = sc[nb][r] * a.scale;
-        if (has_rel) s += relh_s[il * a.kh + jh[nb]] + relw_s[il * a.kw + jw[nb]];
-        const bool valid = j < kv_len && (!a.causal || j <= pos0 + i);
-        s = valid ? s : -INFINITY;
-        sc[nb][r] = s;
-        mx = fmaxf(mx, s);
+        sc[nb] = float4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < HDK / KS; ++kk)
+          sc[nb] = M_::mma(qf[rb][kk], M_::lds(&Ks[(nb * 16 + (lane & 15)) * LDK + kk * KS], lane), sc[nb]);
       }
-#pragma unroll
-      for (int off = 1; off < 16; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
-      const float m_new = fmaxf(m_run[r], mx);
-      const float mref = m_new == -INFINITY ? 0.f : m_new;
-      const float alpha = M_::fexp(m_run[r] - mref);  // m_run = -inf -> 0
-      float rs = 0.f;
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb) {
-        const float p = M_::fexp(sc[nb][r] - mref);  // masked: exp(-inf) = 0
-        rs += p;
-        Pw[(4 * (lane >> 4) + r) * LDP + nb * 16 + (lane & 15)] = from_f32<T>(p);
+      if constexpr (!BF) {
+        // hipcc/ROCm 7.2 under-pads the VALU read of a v_mfma_f32_16x16x4_f32 result on gfx950
+        // (40-cycle dependent latency, MI355X_MICROARCH "cycle constants"): the LAST accumulator
+        // register (r = 3) was read before the final k-step had landed -- rows 3,7,11,15 of every
+        // tile came out slightly wrong.  Pad explicitly before the first VALU use.
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 15");
+        asm volatile("s_nop 15");
+        asm volatile("s_nop 15");
+        __builtin_amdgcn_sched_barrier(0);
       }
-      l_run[r] = l_run[r] * alpha + rs;
-      m_run[r] = m_new;
+      // ---- scale, bias, mask, online softmax ------------------------------------------------
+      __builtin_amdgcn_wave_barrier();  // previous row-block's P reads precede these P writes
+      float al[4];
 #pragma unroll
-      for (int d = 0; d < DB; ++d) o[d][r] *= alpha;
+      for (int r = 0; r < 4; ++r) {
+        const int il = lrow0 + 4 * (lane >> 4) + r, i = q0 + il;
+        float sv[NB];  // scores of this row as scalars (never write through a vector-element lvalue)
+        float mx = -INFINITY;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          const int j = kt + nb * 16 + (lane & 15);
+          const float raw = sc[nb][r];
+          float s = raw * a.scale;
+          if (has_rel) s += relh_s[il * a.kh + jh[nb]] + relw_s[il * a.kw + jw[nb]];
+          const bool valid = j < kv_len && (!a.causal || j <= pos0 + i);
+          s = valid ? s : -INFINITY;
+          sv[nb] = s;
+          mx = fmaxf(mx, s);
+        }
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+        const float m_new = fmaxf(m_run[rb][r], mx);
+        const float mref = m_new == -INFINITY ? 0.f : m_new;
+        al[r] = M_::fexp(m_run[rb][r] - mref);  // m_run = -inf -> 0
+        float rs = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          const float p = M_::fexp(sv[nb] - mref);  // masked: exp(-inf) = 0
+          rs += p;
+          Pw[(4 * (lane >> 4) + r) * LDP + nb * 16 + (lane & 15)] = from_f32<T>(p);
+        }
+        l_run[rb][r] = l_run[rb][r] * al[r] + rs;
+        m_run[rb][r] = m_new;
+      }
+      {
+        const float4v av = float4v{al[0], al[1], al[2], al[3]};
+#pragma unroll
+        for (int d = 0; d < DB; ++d) o[rb][d] *= av;
+      }
+      // P is wave-private, but the writes must have LANDED before other lanes' data is read back
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      // ---- O += P V -------------------------------------------------------------------------
+#pragma unroll
+      for (int kk = 0; kk < BKV / KS; ++kk) {
+        const typename M_::Frag pf = M_::lds(&Pw[(lane & 15) * LDP + kk * KS], lane);
+        if constexpr (BF) {
+          // lane -> (row q, 4 columns p) of its 16-lane group's 4x16 block; k-group g = lane>>4
+          const uint32_t vaddr =
+              (uint32_t)(uintptr_t)(reinterpret_cast<const char*>(Vs) - smem) +
+              (uint32_t)((kk * 32 + 8 * (lane >> 4) + ((lane & 15) >> 2)) * LDV + 4 * (lane & 3)) * 2u;
+          constexpr int ROW4 = 4 * LDV * 2;
+          uint4v vf[DB];
+          if constexpr (DB >= 4) lds_tr_frag4<ROW4>(vaddr, vf[0], vf[1], vf[2], vf[3]);
+          if constexpr (DB == 8) lds_tr_frag4<ROW4>(vaddr + 128, vf[4], vf[5], vf[6], vf[7]);
+          if constexpr (DB == 5) lds_tr_frag1<ROW4>(vaddr + 128, vf[4]);
+          if constexpr (DB < 4) {
+#pragma unroll
+            for (int d = 0; d < DB; ++d) lds_tr_frag1<ROW4>(vaddr + 32 * d, vf[d]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int d = 0; d < DB; ++d) o[rb][d] = M_::mma(pf, __builtin_bit_cast(short8, vf[d]), o[rb][d]);
+        } else {
+#pragma unroll
+          for (int d = 0; d < DB; ++d) {
+            const typename M_::Frag vf = Vs[(kk * KS + (lane >> 4)) * LDV + d * 16 + (lane & 15)];
+            o[rb][d] = M_::mma(pf, vf, o[rb][d]);
+          }
+        }
+      }
     }
-    __syncthreads();  // P visible (wave-local data, but keeps the LDS ordering simple)
-
-    // ---- O += P V ---------------------------------------------------------------------------
-#pragma unroll
-    for (int kk = 0; kk < BKV / KS; ++kk) {
-      const typename M_::Frag pf = M_::lds(&Pw[(lane & 15) * LDP + kk * KS], lane);
-#pragma unroll
-      for (int d = 0; d < DB; ++d) {
-        typename M_::Frag vf;
-        if constexpr (VT)
-          vf = M_::lds(&Vs[(d * 16 + (lane & 15)) * LDV + kk * KS], lane);
-        else
-          vf = Vs[(kk * KS + (lane >> 4)) * LDV + d * 16 + (lane & 15)];
-        o[d] = M_::mma(pf, vf, o[d]);
-      }
-    }
-    __syncthreads();  // K/V/P tiles free for the next iteration
+    __syncthreads();  // K/V tiles free for the next iteration
   }
 
   // ---- normalise + store --------------------------------------------------------------------
   T* Ob = reinterpret_cast<T*>(a.O) + (int64_t)b * a.o_bs + (int64_t)h * a.o_hs;
   float* Obf = reinterpret_cast<float*>(a.O) + (int64_t)b * a.o_bs + (int64_t)h * a.o_hs;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    float l = l_run[r];
+  for (int rb = 0; rb < RB; ++rb) {
 #pragma unroll
-    for (int off = 1; off < 16; off <<= 1) l += __shfl_xor(l, off, 64);
-    const int i = q0 + irow0 + r;
-    if (i >= q_len) continue;
-    const float inv = l > 0.f ? 1.f / l : 0.f;
+    for (int r = 0; r < 4; ++r) {
+      float l = l_run[rb][r];
 #pragma unroll
-    for (int d = 0; d < DB; ++d) {
-      const int64_t off = (int64_t)i * a.o_rs + d * 16 + (lane & 15);
-      if (a.o_f32)
-        Obf[off] = o[d][r] * inv;
-      else
-        Ob[off] = from_f32<T>(o[d][r] * inv);
+      for (int off = 1; off < 16; off <<= 1) l += __shfl_xor(l, off, 64);
+      const int i = q0 + wrow0 + rb * 16 + 4 * (lane >> 4) + r;
+      if (i < q_len) {
+        const float inv = l > 0.f ? 1.f / l : 0.f;
+#pragma unroll
+        for (int d = 0; d < DB; ++d) {
+          const int64_t off = (int64_t)i * a.o_rs + d * 16 + (lane & 15);
+          if (a.o_f32)
+            Obf[off] = o[rb][d][r] * inv;
+          else
+            Ob[off] = from_f32<T>(o[rb][d][r] * inv);
+        }
+      }
     }
   }
 }
 
-template <typename T, int HD>
-static void attn_launch(const AttnArgs& a, hipStream_t s) {
+template <typename T, int HD, int RB>
+static void attn_launch_rb(const AttnArgs& a, hipStream_t s) {
   constexpr int KS = AMma<T>::KS, VEC = AMma<T>::VEC, BKV = AttnTile<T>::BKV;
   constexpr int HDK = (HD + KS - 1) / KS * KS, LDK = HDK + VEC;
-  constexpr bool VT = sizeof(T) == 2;
-  constexpr int LDV = VT ? BKV + VEC : HD + VEC, LDP = BKV + VEC;
-  size_t lds = sizeof(T) * (BKV * LDK + (VT ? HD * LDV : BKV * LDV) + 4 * 16 * LDP);
-  if (a.rel_h || a.rel_p) lds += sizeof(float) * 64 * (a.kh + a.kw);
+  constexpr int LDV = HD + VEC, LDP = BKV + VEC, BQ = 64 * RB;
+  size_t lds = sizeof(T) * (BKV * LDK + BKV * LDV + 4 * 16 * LDP);
+  if (a.rel_h || a.rel_p) lds += sizeof(float) * BQ * (a.kh + a.kw);
   if (lds > 160 * 1024) throw std::runtime_error("attention: LDS budget exceeded");
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<T, HD>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<T, HD, RB>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
-  dim3 grid(cdiv(a.Sq, 64), a.H, a.B);
+  dim3 grid(cdiv(a.Sq, BQ), a.H, a.B);
   static const std::string tag = std::string(sizeof(T) == 2 ? "attn_bf16_hd" : "attn_f32_hd") + std::to_string(HD);
   const double flops = 4.0 * a.B * a.H * (double)a.Sq * a.Sk * HD * (a.causal ? 0.5 : 1.0);
   const double bytes = (double)a.B * a.H * HD * sizeof(T) * (2.0 * a.Sq + 2.0 * a.Sk);
   ProfScope prof(tag.c_str(), flops, bytes, s);
-  hipLaunchKernelGGL((attn_kernel<T, HD>), grid, dim3(256), lds, s, a);
+  hipLaunchKernelGGL((attn_kernel<T, HD, RB>), grid, dim3(256), lds, s, a);
+}
+
+template <typename T, int HD>
+static void attn_launch(const AttnArgs& a, hipStream_t s) {
+  // One 16-row block per wave.  RB = 2 / 4 (more MFMAs per staged K/V tile) was measured SLOWER on
+  // MI355X: 164-255 VGPRs leave one wave per SIMD and the loop is issue/latency- not staging-bound
+  // (SAM window 81 -> 87 / 133 us, SAM global 694 -> 1010 us per layer).
+  attn_launch_rb<T, HD, 1>(a, s);
 }
 
 template <typename T>
