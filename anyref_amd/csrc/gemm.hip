@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <stdexcept>
 #include <utility>
+#include <vector>
 #include "kernels.h"
 
 namespace anyref {
@@ -210,10 +211,83 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a) {  // 2 waves/
   gemm_epilogue<T, BM, BN>(a, acc, m0, n0, z, lane, wr, wc);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Split-K for skinny, deep GEMMs (LLM prefill o_proj / down_proj at M = 320, CLIP fc2): with one
+// 64x64 workgroup per CU and a single tile of prefetch they are HBM-LATENCY bound (0.58 us per
+// k-step measured, 10x the MFMA time).  K is cut into `splits` slices run as the batch dimension
+// into an f32 slab buffer; a second tiny kernel sums the slabs in a fixed order (deterministic, no
+// float atomics) and applies bias / activation / residual.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void splitk_reduce_kernel(const float* __restrict__ slabs, int splits, int64_t slab_stride, GemmArgs a) {
+  const int64_t total = (int64_t)a.M * a.N / 4;
+  float* Cf = reinterpret_cast<float*>(a.C);
+  T* Ct = reinterpret_cast<T*>(a.C);
+  for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < total; v += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e = v * 4;
+    const int m = (int)(e / a.N), n = (int)(e % a.N);
+    float4v acc = *reinterpret_cast<const float4v*>(slabs + e);
+    for (int z = 1; z < splits; ++z) acc += *reinterpret_cast<const float4v*>(slabs + z * slab_stride + e);
+    acc *= a.alpha;
+    if (a.bias) acc += *reinterpret_cast<const float4v*>(a.bias + n);
+    acc = float4v{apply_act(acc[0], a.act), apply_act(acc[1], a.act), apply_act(acc[2], a.act), apply_act(acc[3], a.act)};
+    if (a.resid) acc += *reinterpret_cast<const float4v*>(a.resid + (int64_t)m * a.ldr + n);
+    if (a.c_f32) {
+      *reinterpret_cast<float4v*>(Cf + (int64_t)m * a.ldc + n) = acc;
+    } else {
+      T* o = Ct + (int64_t)m * a.ldc + n;
+      o[0] = from_f32<T>(acc[0]); o[1] = from_f32<T>(acc[1]); o[2] = from_f32<T>(acc[2]); o[3] = from_f32<T>(acc[3]);
+    }
+  }
+}
+
+// per-stream slab workspace (grown on demand; streams never share one)
+static float* splitk_workspace(hipStream_t s, size_t bytes) {
+  struct Ws { hipStream_t s; float* p; size_t cap; };
+  static thread_local std::vector<Ws> pool;
+  for (auto& w : pool)
+    if (w.s == s) {
+      if (w.cap < bytes) {
+        HIP_TRY(hipStreamSynchronize(s));
+        (void)hipFree(w.p);
+        HIP_TRY(hipMalloc((void**)&w.p, bytes));
+        w.cap = bytes;
+      }
+      return w.p;
+    }
+  Ws w{s, nullptr, bytes};
+  HIP_TRY(hipMalloc((void**)&w.p, bytes));
+  pool.push_back(w);
+  return w.p;
+}
+
 template <typename T>
 void launch_gemm(const GemmArgs& a_in, hipStream_t s) {
   GemmArgs a = a_in;
   constexpr int VEC = Mma<T>::VEC;
+  // ---- split-K decision: few 64x64 tiles, deep K, plain row-major output ----
+  if (sizeof(T) == 2 && a.batch == 1 && !a.row_map && a.M <= 512 && a.K >= 2048 && a.N % 4 == 0 && a.ldc % 4 == 0 &&
+      (!a.resid || a.ldr % 4 == 0)) {
+    const int64_t tiles = (int64_t)cdiv(a.M, 64) * cdiv(a.N, 64);
+    int splits = 1;
+    while (splits < 8 && tiles * splits < 1024 && (a.K / (splits * 2)) % 64 == 0 && a.K / (splits * 2) >= 512) splits *= 2;
+    if (splits > 1) {
+      const int64_t slab = (int64_t)a.M * a.N;
+      float* ws = splitk_workspace(s, (size_t)splits * slab * sizeof(float));
+      GemmArgs g = a;
+      g.K = a.K / splits;
+      g.batch = splits;
+      g.sA = g.K;   // column offset inside the same rows
+      g.sW = g.K;
+      g.C = ws; g.ldc = a.N; g.sC = slab; g.c_f32 = 1;
+      g.bias = nullptr; g.resid = nullptr; g.act = ACT_NONE; g.alpha = 1.f;
+      launch_gemm<T>(g, s);
+      const int64_t total = slab / 4;
+      const int grid = (int)(cdiv64(total, 256) < 2048 ? cdiv64(total, 256) : 2048);
+      hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(grid), dim3(256), 0, s, ws, splits, slab, a);
+      return;
+    }
+  }
   constexpr int BK = sizeof(T) == 2 ? 64 : 16;
   if (a.M <= 0 || a.N <= 0) return;
   if (a.K % VEC || a.lda % VEC || a.ldw % VEC || ((uintptr_t)a.A & 15) || ((uintptr_t)a.W & 15) ||
