@@ -56,75 +56,87 @@ struct AttnTile {
   static constexpr int BKV = sizeof(T) == 2 ? 64 : 32;
 };
 
-// ---- B-operand fragments of P.V from a ROW-major V tile --------------------------------------
-// f32: one scalar per lane (B[k = lane>>4][n = lane&15]).
-// bf16: the 8 k-values of a lane's column sit in 8 different rows; gfx950's ds_read_b64_tr_b16
-// (guide T10) transposes 4 rows x 16 columns per 16-lane group in the LDS read itself, so V is
-// staged with plain 16-byte row stores (no 2-byte transposing scatter).  Lane 4q+p of a group
-// supplies the address of row q, columns 4p..4p+3; lane i receives column i of the 4 rows.  Two
-// reads (rows +0 and +4) make one 8-element fragment.  Reads and their wait live in ONE asm
-// statement (guide §5.7 form (i)); EXEC is all ones here (only wave-uniform control flow above).
+// ---------------------------------------------------------------------------------------------
+// Transposed formulation.  Every wave owns 16 queries and computes, per K/V tile,
+//     S^T = K Q^T          (16x16 tiles: key on the accumulator ROW, query on the lane COLUMN)
+//     P^T = softmax columns (each lane owns ONE query: max / sum are lane-local over the tile's
+//                            keys + two xor-shuffles across the 4 lane groups)
+//     O^T += V^T P^T       (bf16: v_mfma_f32_16x16x16_bf16, whose B operand layout B[k = 4g+j][n]
+//                            IS the accumulator layout of S^T, so P never leaves registers;
+//                            f32: v_mfma_f32_16x16x4_f32 with k-slot g <- key 4g+r)
+// so there is no P round trip through LDS, no per-row replication of the softmax statistics, and
+// the output leaves as 4 consecutive head-dim values per lane.
+// V^T fragments (A operand, A[d][key 4g+j]) come from the ROW-major V tile through
+// ds_read_b64_tr_b16 (guide T10): per 16-lane group a 4-row x 16-column block is transposed by the
+// LDS read itself; lane 4q+p supplies the address of row q, columns 4p..4p+3 and lane i receives
+// column i of the 4 rows.  K and V are staged with plain 16-byte row stores.
+// ---------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(2))) uint32_t uint2v;
+typedef __attribute__((ext_vector_type(4))) short short4v;
 
-template <int ROW4>  // byte offset of 4 rows
-__device__ inline void lds_tr_frag1(uint32_t addr, uint4v& f0) {
-  uint2v a0, b0;
-  asm volatile(
-      "ds_read_b64_tr_b16 %0, %2\n\t"
-      "ds_read_b64_tr_b16 %1, %2 offset:%3\n\t"
-      "s_waitcnt lgkmcnt(0)"
-      : "=&v"(a0), "=&v"(b0)
-      : "v"(addr), "i"(ROW4)
-      : "memory");
-  f0 = uint4v{a0[0], a0[1], b0[0], b0[1]};
+// DB transposed 4x16 blocks (consecutive 16-column blocks of the same 4 rows) in ONE asm statement
+// with their wait (guide §5.7 form (i)); EXEC is all ones (only wave-uniform control flow above).
+template <int DB>
+__device__ inline void lds_tr_blocks(uint32_t addr, uint2v (&f)[DB]);
+template <>
+__device__ inline void lds_tr_blocks<1>(uint32_t addr, uint2v (&f)[1]) {
+  asm volatile("ds_read_b64_tr_b16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(f[0]) : "v"(addr) : "memory");
 }
-template <int ROW4>
-__device__ inline void lds_tr_frag4(uint32_t addr, uint4v& f0, uint4v& f1, uint4v& f2, uint4v& f3) {
-  uint2v a0, b0, a1, b1, a2, b2, a3, b3;
+template <>
+__device__ inline void lds_tr_blocks<2>(uint32_t addr, uint2v (&f)[2]) {
+  asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:32\n\ts_waitcnt lgkmcnt(0)"
+               : "=&v"(f[0]), "=&v"(f[1]) : "v"(addr) : "memory");
+}
+template <>
+__device__ inline void lds_tr_blocks<4>(uint32_t addr, uint2v (&f)[4]) {
   asm volatile(
-      "ds_read_b64_tr_b16 %0, %8\n\t"
-      "ds_read_b64_tr_b16 %1, %8 offset:%9\n\t"
-      "ds_read_b64_tr_b16 %2, %8 offset:32\n\t"
-      "ds_read_b64_tr_b16 %3, %8 offset:%10\n\t"
-      "ds_read_b64_tr_b16 %4, %8 offset:64\n\t"
-      "ds_read_b64_tr_b16 %5, %8 offset:%11\n\t"
-      "ds_read_b64_tr_b16 %6, %8 offset:96\n\t"
-      "ds_read_b64_tr_b16 %7, %8 offset:%12\n\t"
-      "s_waitcnt lgkmcnt(0)"
-      : "=&v"(a0), "=&v"(b0), "=&v"(a1), "=&v"(b1), "=&v"(a2), "=&v"(b2), "=&v"(a3), "=&v"(b3)
-      : "v"(addr), "i"(ROW4), "i"(ROW4 + 32), "i"(ROW4 + 64), "i"(ROW4 + 96)
-      : "memory");
-  f0 = uint4v{a0[0], a0[1], b0[0], b0[1]};
-  f1 = uint4v{a1[0], a1[1], b1[0], b1[1]};
-  f2 = uint4v{a2[0], a2[1], b2[0], b2[1]};
-  f3 = uint4v{a3[0], a3[1], b3[0], b3[1]};
+      "ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %4 offset:32\n\t"
+      "ds_read_b64_tr_b16 %2, %4 offset:64\n\tds_read_b64_tr_b16 %3, %4 offset:96\n\ts_waitcnt lgkmcnt(0)"
+      : "=&v"(f[0]), "=&v"(f[1]), "=&v"(f[2]), "=&v"(f[3]) : "v"(addr) : "memory");
+}
+template <>
+__device__ inline void lds_tr_blocks<5>(uint32_t addr, uint2v (&f)[5]) {
+  asm volatile(
+      "ds_read_b64_tr_b16 %0, %5\n\tds_read_b64_tr_b16 %1, %5 offset:32\n\t"
+      "ds_read_b64_tr_b16 %2, %5 offset:64\n\tds_read_b64_tr_b16 %3, %5 offset:96\n\t"
+      "ds_read_b64_tr_b16 %4, %5 offset:128\n\ts_waitcnt lgkmcnt(0)"
+      : "=&v"(f[0]), "=&v"(f[1]), "=&v"(f[2]), "=&v"(f[3]), "=&v"(f[4]) : "v"(addr) : "memory");
+}
+template <>
+__device__ inline void lds_tr_blocks<8>(uint32_t addr, uint2v (&f)[8]) {
+  asm volatile(
+      "ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %8 offset:32\n\t"
+      "ds_read_b64_tr_b16 %2, %8 offset:64\n\tds_read_b64_tr_b16 %3, %8 offset:96\n\t"
+      "ds_read_b64_tr_b16 %4, %8 offset:128\n\tds_read_b64_tr_b16 %5, %8 offset:160\n\t"
+      "ds_read_b64_tr_b16 %6, %8 offset:192\n\tds_read_b64_tr_b16 %7, %8 offset:224\n\ts_waitcnt lgkmcnt(0)"
+      : "=&v"(f[0]), "=&v"(f[1]), "=&v"(f[2]), "=&v"(f[3]), "=&v"(f[4]), "=&v"(f[5]), "=&v"(f[6]), "=&v"(f[7])
+      : "v"(addr) : "memory");
 }
 
-// Workgroup = 4 waves; every wave owns RB row-blocks of 16 queries (BQ = 64*RB queries per
-// workgroup).  Only RB = 1 is instantiated (see attn_launch).
-template <typename T, int HD, int RB>
+__device__ inline uint32_t pack_bf16x2(float lo, float hi) { return (uint32_t)f2bf(lo).x | ((uint32_t)f2bf(hi).x << 16); }
+
+template <typename T, int HD>
 __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
   using M_ = AMma<T>;
   constexpr int KS = M_::KS, VEC = M_::VEC;
   constexpr bool BF = sizeof(T) == 2;
   constexpr int BKV = AttnTile<T>::BKV;
-  constexpr int BQ = 64 * RB;
+  constexpr int BQ = 64;
   constexpr int HDK = (HD + KS - 1) / KS * KS;  // QK^T contraction length (zero padded)
   constexpr int LDK = HDK + VEC;                // K tile row stride
   constexpr int LDV = HD + VEC;                 // V tile row stride (row-major [key][d])
-  constexpr int LDP = BKV + VEC;
-  constexpr int NB = BKV / 16;  // key blocks of one tile
-  constexpr int DB = HD / 16;   // output d blocks
+  constexpr int NB = BKV / 16;                  // key blocks of one tile
+  constexpr int DB = HD / 16;                   // output d blocks
   static_assert(HD % 16 == 0, "head dim must be a multiple of 16");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* Ks = reinterpret_cast<T*>(smem);
   T* Vs = Ks + BKV * LDK;
-  T* Ps = Vs + BKV * LDV;
-  float* relh_s = reinterpret_cast<float*>(Ps + 4 * 16 * LDP);
+  float* relh_s = reinterpret_cast<float*>(Vs + BKV * LDV);
   float* relw_s = relh_s + BQ * a.kh;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int qi = lane & 15, g = lane >> 4;  // this lane's query (column) and lane group
   const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * BQ;
   const int kv_len = a.kv_len ? a.kv_len[b] : a.Sk;
   const int q_len = a.q_len ? a.q_len[b] : a.Sq;
@@ -140,16 +152,14 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
   const T* Kb = reinterpret_cast<const T*>(a.K) + (int64_t)b * a.k_bs + (int64_t)h * a.k_hs;
   const T* Vb = reinterpret_cast<const T*>(a.V) + (int64_t)b * a.v_bs + (int64_t)h * a.v_hs;
 
-  // Q fragments (A operand) of this wave's RB row-blocks; row-block rb starts at local row wrow0 + 16*rb
-  const int wrow0 = wave * 16 * RB;
-  typename M_::Frag qf[RB][HDK / KS];
+  // Q fragments, used as the B operand of S^T = K Q^T: B[k = d][n = query lane&15]
+  const int il = wave * 16 + qi, iq = q0 + il;  // local / global query of this lane
+  const bool q_ok = iq < q_len;
+  typename M_::Frag qf[HDK / KS];
+  {
+    const T* qrow = Qb + (int64_t)(q_ok ? iq : 0) * a.q_rs;
 #pragma unroll
-  for (int rb = 0; rb < RB; ++rb) {
-    const int qr = q0 + wrow0 + rb * 16 + (lane & 15);
-    const bool ok = qr < q_len;
-    const T* qrow = Qb + (int64_t)(ok ? qr : 0) * a.q_rs;
-#pragma unroll
-    for (int kk = 0; kk < HDK / KS; ++kk) qf[rb][kk] = M_::glb(qrow, kk * KS, lane, ok, HD);
+    for (int kk = 0; kk < HDK / KS; ++kk) qf[kk] = M_::glb(qrow, kk * KS, lane, q_ok, HD);
   }
   const bool has_rel = a.rel_h != nullptr || a.rel_p != nullptr;
   if (a.rel_p) {
@@ -177,21 +187,24 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
       relw_s[i] = q0 + r < q_len ? rw[(int64_t)(q0 + r) * a.kw + c] : 0.f;
     }
   }
-
-  float m_run[RB][4], l_run[RB][4];
-  float4v o[RB][DB];
+  // global-attention fast path: the key tile is exactly one bias row (kw == BKV, tiles aligned), so
+  // the kw-term of this lane's 16 keys never changes and the kh-term is one value per tile
+  const bool rel_fast = has_rel && a.kw == BKV;
+  // general path: j / kw by multiply-shift, exact for j < 4096 and kw <= 64 (error j / 2^20 < 1 / kw)
+  const unsigned kw_magic = has_rel ? (1u << 20) / (unsigned)a.kw + 1u : 0u;
+  float relw_reg[NB][4];
+  if (rel_fast) {
+    __syncthreads();
 #pragma unroll
-  for (int rb = 0; rb < RB; ++rb) {
+    for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      m_run[rb][r] = -INFINITY;
-      l_run[rb][r] = 0.f;
-    }
-#pragma unroll
-    for (int d = 0; d < DB; ++d) o[rb][d] = float4v{0.f, 0.f, 0.f, 0.f};
+      for (int r = 0; r < 4; ++r) relw_reg[nb][r] = relw_s[il * a.kw + nb * 16 + 4 * g + r];
   }
 
-  T* Pw = Ps + wave * 16 * LDP;  // wave-private P staging (C layout -> A operand)
+  float m_run = -INFINITY, l_run = 0.f;  // running max / (partial) sum of THIS lane's query
+  float4v ot[DB];                        // O^T tiles: row = d (4g+r), col = query
+#pragma unroll
+  for (int d = 0; d < DB; ++d) ot[d] = float4v{0.f, 0.f, 0.f, 0.f};
 
   for (int kt = 0; kt < kv_end; kt += BKV) {
     // ---- stage K [BKV][HDK] and V [BKV][HD], both row-major, 16-byte vectors ------------------
@@ -213,173 +226,140 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
     }
     __syncthreads();
 
-    int jh[NB], jw[NB];
-    if (has_rel) {
+    // wave-uniform skips: rows past the end / tile entirely in the causal future of this row block
+    const bool active = q0 + wave * 16 < q_len && !(a.causal && kt > pos0 + q0 + wave * 16 + 15);
+    if (active) {
+      // ---- S^T = K Q^T ------------------------------------------------------------------------
+      float4v st[NB];
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
-        const int j = kt + nb * 16 + (lane & 15);
-        jh[nb] = j / a.kw;
-        jw[nb] = j % a.kw;
-        if (jh[nb] >= a.kh) {  // masked keys beyond kv_len: keep LDS reads in range
-          jh[nb] = 0;
-          jw[nb] = 0;
-        }
-      }
-    }
-#pragma unroll
-    for (int rb = 0; rb < RB; ++rb) {
-      const int lrow0 = wrow0 + rb * 16;      // first local row of this row-block
-      if (q0 + lrow0 >= q_len) continue;      // wave-uniform: nothing to do for rows past the end
-      if (a.causal && kt > pos0 + q0 + lrow0 + 15) continue;  // tile entirely in the future of these rows
-      // ---- S = Q K^T ------------------------------------------------------------------------
-      float4v sc[NB];
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb) {
-        sc[nb] = float4v{0.f, 0.f, 0.f, 0.f};
+        st[nb] = float4v{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < HDK / KS; ++kk)
-          sc[nb] = M_::mma(qf[rb][kk], M_::lds(&Ks[(nb * 16 + (lane & 15)) * LDK + kk * KS], lane), sc[nb]);
+          st[nb] = M_::mma(M_::lds(&Ks[(nb * 16 + qi) * LDK + kk * KS], lane), qf[kk], st[nb]);
       }
       if constexpr (!BF) {
         // hipcc/ROCm 7.2 under-pads the VALU read of a v_mfma_f32_16x16x4_f32 result on gfx950
-        // (40-cycle dependent latency, MI355X_MICROARCH "cycle constants"): the LAST accumulator
-        // register (r = 3) was read before the final k-step had landed -- rows 3,7,11,15 of every
-        // tile came out slightly wrong.  Pad explicitly before the first VALU use.
+        // (40-cycle dependent latency): the LAST accumulator register was read before the final
+        // k-step had landed (every 4th key/row slightly wrong).  Pad before the first VALU use.
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_nop 15");
-        asm volatile("s_nop 15");
-        asm volatile("s_nop 15");
+        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15");
         __builtin_amdgcn_sched_barrier(0);
       }
-      // ---- scale, bias, mask, online softmax ------------------------------------------------
-      __builtin_amdgcn_wave_barrier();  // previous row-block's P reads precede these P writes
-      float al[4];
+      // ---- scale, bias, mask; column softmax of this lane's query -------------------------------
+      float sv[NB][4];
+      float mx = -INFINITY;
+      const float relh_tile = rel_fast ? relh_s[il * a.kh + kt / BKV] : 0.f;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int il = lrow0 + 4 * (lane >> 4) + r, i = q0 + il;
-        float sv[NB];  // scores of this row as scalars (never write through a vector-element lvalue)
-        float mx = -INFINITY;
+      for (int nb = 0; nb < NB; ++nb) {
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-          const int j = kt + nb * 16 + (lane & 15);
-          const float raw = sc[nb][r];
-          float s = raw * a.scale;
-          if (has_rel) s += relh_s[il * a.kh + jh[nb]] + relw_s[il * a.kw + jw[nb]];
-          const bool valid = j < kv_len && (!a.causal || j <= pos0 + i);
+        for (int r = 0; r < 4; ++r) {
+          const int j = kt + nb * 16 + 4 * g + r;
+          float s = st[nb][r] * a.scale;
+          if (rel_fast) {
+            s += relh_tile + relw_reg[nb][r];
+          } else if (has_rel) {
+            int jh = (int)(((unsigned)j * kw_magic) >> 20), jw = j - jh * a.kw;
+            if (jh >= a.kh) jh = 0, jw = 0;  // masked keys beyond kv_len: keep LDS reads in range
+            s += relh_s[il * a.kh + jh] + relw_s[il * a.kw + jw];
+          }
+          const bool valid = j < kv_len && (!a.causal || j <= pos0 + iq);
           s = valid ? s : -INFINITY;
-          sv[nb] = s;
+          sv[nb][r] = s;
           mx = fmaxf(mx, s);
         }
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx);
+      const float mref = m_new == -INFINITY ? 0.f : m_new;
+      const float alpha = M_::fexp(m_run - mref);  // m_run = -inf -> 0
+      float rs = 0.f;
 #pragma unroll
-        for (int off = 1; off < 16; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
-        const float m_new = fmaxf(m_run[rb][r], mx);
-        const float mref = m_new == -INFINITY ? 0.f : m_new;
-        al[r] = M_::fexp(m_run[rb][r] - mref);  // m_run = -inf -> 0
-        float rs = 0.f;
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          sv[nb][r] = M_::fexp(sv[nb][r] - mref);  // masked: exp(-inf) = 0
+          rs += sv[nb][r];
+        }
+      l_run = l_run * alpha + rs;
+      m_run = m_new;
+#pragma unroll
+      for (int d = 0; d < DB; ++d) ot[d] *= alpha;
+      // ---- O^T += V^T P^T -----------------------------------------------------------------------
+      if constexpr (BF) {
+        // this lane's address inside its group's 4x16 block: row q = (lane&15)>>2, columns 4p
+        const uint32_t vbase = (uint32_t)(reinterpret_cast<const char*>(Vs) - smem) +  // dynamic LDS starts at 0
+                               (uint32_t)((4 * g + (qi >> 2)) * LDV + 4 * (qi & 3)) * 2u;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
-          const float p = M_::fexp(sv[nb] - mref);  // masked: exp(-inf) = 0
-          rs += p;
-          Pw[(4 * (lane >> 4) + r) * LDP + nb * 16 + (lane & 15)] = from_f32<T>(p);
-        }
-        l_run[rb][r] = l_run[rb][r] * al[r] + rs;
-        m_run[rb][r] = m_new;
-      }
-      {
-        const float4v av = float4v{al[0], al[1], al[2], al[3]};
-#pragma unroll
-        for (int d = 0; d < DB; ++d) o[rb][d] *= av;
-      }
-      // P is wave-private, but the writes must have LANDED before other lanes' data is read back
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_wave_barrier();
-      // ---- O += P V -------------------------------------------------------------------------
-#pragma unroll
-      for (int kk = 0; kk < BKV / KS; ++kk) {
-        const typename M_::Frag pf = M_::lds(&Pw[(lane & 15) * LDP + kk * KS], lane);
-        if constexpr (BF) {
-          // lane -> (row q, 4 columns p) of its 16-lane group's 4x16 block; k-group g = lane>>4
-          const uint32_t vaddr =
-              (uint32_t)(uintptr_t)(reinterpret_cast<const char*>(Vs) - smem) +
-              (uint32_t)((kk * 32 + 8 * (lane >> 4) + ((lane & 15) >> 2)) * LDV + 4 * (lane & 3)) * 2u;
-          constexpr int ROW4 = 4 * LDV * 2;
-          uint4v vf[DB];
-          if constexpr (DB >= 4) lds_tr_frag4<ROW4>(vaddr, vf[0], vf[1], vf[2], vf[3]);
-          if constexpr (DB == 8) lds_tr_frag4<ROW4>(vaddr + 128, vf[4], vf[5], vf[6], vf[7]);
-          if constexpr (DB == 5) lds_tr_frag1<ROW4>(vaddr + 128, vf[4]);
-          if constexpr (DB < 4) {
-#pragma unroll
-            for (int d = 0; d < DB; ++d) lds_tr_frag1<ROW4>(vaddr + 32 * d, vf[d]);
-          }
+          uint2v vt[DB];
+          lds_tr_blocks<DB>(vbase + (uint32_t)(nb * 16 * LDV * 2), vt);
           __builtin_amdgcn_sched_barrier(0);
+          const uint2v pb = uint2v{pack_bf16x2(sv[nb][0], sv[nb][1]), pack_bf16x2(sv[nb][2], sv[nb][3])};
 #pragma unroll
-          for (int d = 0; d < DB; ++d) o[rb][d] = M_::mma(pf, __builtin_bit_cast(short8, vf[d]), o[rb][d]);
-        } else {
-#pragma unroll
-          for (int d = 0; d < DB; ++d) {
-            const typename M_::Frag vf = Vs[(kk * KS + (lane >> 4)) * LDV + d * 16 + (lane & 15)];
-            o[rb][d] = M_::mma(pf, vf, o[rb][d]);
-          }
+          for (int d = 0; d < DB; ++d)
+            ot[d] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(short4v, vt[d]),
+                                                              __builtin_bit_cast(short4v, pb), ot[d], 0, 0, 0);
         }
+      } else {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float* vrow = reinterpret_cast<const float*>(Vs) + (nb * 16 + 4 * g + r) * LDV + qi;  // k-slot g <- key 4g+r
+#pragma unroll
+            for (int d = 0; d < DB; ++d) ot[d] = M_::mma(vrow[d * 16], sv[nb][r], ot[d]);
+          }
       }
     }
     __syncthreads();  // K/V tiles free for the next iteration
   }
 
-  // ---- normalise + store --------------------------------------------------------------------
-  T* Ob = reinterpret_cast<T*>(a.O) + (int64_t)b * a.o_bs + (int64_t)h * a.o_hs;
-  float* Obf = reinterpret_cast<float*>(a.O) + (int64_t)b * a.o_bs + (int64_t)h * a.o_hs;
+  // ---- normalise + store: lane (query qi, group g) holds O[query][d = 16*db + 4g + r] ------------
+  l_run += __shfl_xor(l_run, 16, 64);
+  l_run += __shfl_xor(l_run, 32, 64);
+  if (q_ok) {
+    const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+    T* Ob = reinterpret_cast<T*>(a.O) + (int64_t)b * a.o_bs + (int64_t)h * a.o_hs + (int64_t)iq * a.o_rs;
+    float* Obf = reinterpret_cast<float*>(a.O) + (int64_t)b * a.o_bs + (int64_t)h * a.o_hs + (int64_t)iq * a.o_rs;
 #pragma unroll
-  for (int rb = 0; rb < RB; ++rb) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float l = l_run[rb][r];
-#pragma unroll
-      for (int off = 1; off < 16; off <<= 1) l += __shfl_xor(l, off, 64);
-      const int i = q0 + wrow0 + rb * 16 + 4 * (lane >> 4) + r;
-      if (i < q_len) {
-        const float inv = l > 0.f ? 1.f / l : 0.f;
-#pragma unroll
-        for (int d = 0; d < DB; ++d) {
-          const int64_t off = (int64_t)i * a.o_rs + d * 16 + (lane & 15);
-          if (a.o_f32)
-            Obf[off] = o[rb][d][r] * inv;
-          else
-            Ob[off] = from_f32<T>(o[rb][d][r] * inv);
-        }
+    for (int d = 0; d < DB; ++d) {
+      const float4v v = ot[d] * inv;
+      const int c = d * 16 + 4 * g;
+      if (a.o_f32) {
+        Obf[c] = v[0]; Obf[c + 1] = v[1]; Obf[c + 2] = v[2]; Obf[c + 3] = v[3];
+      } else if constexpr (BF) {
+        reinterpret_cast<uint16_t*>(Ob)[c] = f2bf(v[0]).x;
+        reinterpret_cast<uint16_t*>(Ob)[c + 1] = f2bf(v[1]).x;
+        reinterpret_cast<uint16_t*>(Ob)[c + 2] = f2bf(v[2]).x;
+        reinterpret_cast<uint16_t*>(Ob)[c + 3] = f2bf(v[3]).x;
+      } else {
+        Ob[c] = v[0]; Ob[c + 1] = v[1]; Ob[c + 2] = v[2]; Ob[c + 3] = v[3];
       }
     }
   }
 }
 
-template <typename T, int HD, int RB>
-static void attn_launch_rb(const AttnArgs& a, hipStream_t s) {
+template <typename T, int HD>
+static void attn_launch(const AttnArgs& a, hipStream_t s) {
   constexpr int KS = AMma<T>::KS, VEC = AMma<T>::VEC, BKV = AttnTile<T>::BKV;
-  constexpr int HDK = (HD + KS - 1) / KS * KS, LDK = HDK + VEC;
-  constexpr int LDV = HD + VEC, LDP = BKV + VEC, BQ = 64 * RB;
-  size_t lds = sizeof(T) * (BKV * LDK + BKV * LDV + 4 * 16 * LDP);
-  if (a.rel_h || a.rel_p) lds += sizeof(float) * BQ * (a.kh + a.kw);
+  constexpr int HDK = (HD + KS - 1) / KS * KS, LDK = HDK + VEC, LDV = HD + VEC;
+  size_t lds = sizeof(T) * (BKV * LDK + BKV * LDV);
+  if (a.rel_h || a.rel_p) lds += sizeof(float) * 64 * (a.kh + a.kw);
   if (lds > 160 * 1024) throw std::runtime_error("attention: LDS budget exceeded");
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<T, HD, RB>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<T, HD>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
-  dim3 grid(cdiv(a.Sq, BQ), a.H, a.B);
+  dim3 grid(cdiv(a.Sq, 64), a.H, a.B);
   static const std::string tag = std::string(sizeof(T) == 2 ? "attn_bf16_hd" : "attn_f32_hd") + std::to_string(HD);
   const double flops = 4.0 * a.B * a.H * (double)a.Sq * a.Sk * HD * (a.causal ? 0.5 : 1.0);
   const double bytes = (double)a.B * a.H * HD * sizeof(T) * (2.0 * a.Sq + 2.0 * a.Sk);
   ProfScope prof(tag.c_str(), flops, bytes, s);
-  hipLaunchKernelGGL((attn_kernel<T, HD, RB>), grid, dim3(256), lds, s, a);
-}
-
-template <typename T, int HD>
-static void attn_launch(const AttnArgs& a, hipStream_t s) {
-  // One 16-row block per wave.  RB = 2 / 4 (more MFMAs per staged K/V tile) was measured SLOWER on
-  // MI355X: 164-255 VGPRs leave one wave per SIMD and the loop is issue/latency- not staging-bound
-  // (SAM window 81 -> 87 / 133 us, SAM global 694 -> 1010 us per layer).
-  attn_launch_rb<T, HD, 1>(a, s);
+  hipLaunchKernelGGL((attn_kernel<T, HD>), grid, dim3(256), lds, s, a);
 }
 
 template <typename T>
