@@ -115,6 +115,8 @@ int anyref_project_audio(anyref_handle* h, void* stream, const float* audio_emb,
 
 int anyref_set_seg_range(anyref_handle* h, int lo, int hi) { GUARD(h, h->m->set_seg_range(lo, hi)); }
 
+int anyref_set_overlap(anyref_handle* h, int on) { GUARD(h, h->m->set_overlap(on != 0)); }
+
 int anyref_profile_enable(anyref_handle* h, int on) {
   GUARD(h, {
     h->m->prof.on = on != 0;

@@ -56,6 +56,9 @@ class ModelBase {
     cfg.seg_lo = lo;
     cfg.seg_hi = hi;
   }
+  // two-stream overlap of the SAM encoder with the LLM decode (default on; measurement harness can
+  // switch it off to time kernels without a co-running stream)
+  void set_overlap(bool on) { overlap_ = on; }
   Profiler prof;
   std::string err;
   int n_unknown = 0;
@@ -73,6 +76,7 @@ class ModelBase {
   std::unordered_map<void*, size_t> allocs_;
   std::map<std::string, RawTensor> raw_;
   bool finalized_ = false;
+  bool overlap_ = true;
 };
 
 std::unique_ptr<ModelBase> make_model(const anyref_config& cfg, int device);

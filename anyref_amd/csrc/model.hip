@@ -12,6 +12,7 @@
 // microseconds and removes its bf16 error from the logits).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "model.h"
@@ -700,6 +701,7 @@ void Model<T>::finalize() {
 
 template <typename T>
 void Model<T>::fork_sam(hipStream_t s, const float* sam_images, int B) {
+  if (!overlap_) return;  // encoder then runs on `s` inside run_tail
   HIP_TRY(hipEventRecord(ev_fork_, s));
   HIP_TRY(hipStreamWaitEvent(s2_, ev_fork_, 0));
   sam_encoder(s2_, sam_images, B, sam_emb_);

@@ -172,6 +172,10 @@ class AnyRefForCausalLM:
         lo, hi = self.cfg.seg_range()
         self._check(self.lib.anyref_set_seg_range(self.h, lo, hi), "set_seg_range")
 
+    def set_overlap(self, on: bool):
+        """SAM encoder on a second stream under the LLM decode (default) or everything on one stream."""
+        self._check(self.lib.anyref_set_overlap(self.h, int(on)), "set_overlap")
+
     # ---- per-kernel timing for bench.py ------------------------------------------------------
     def profile_enable(self, on: bool, only_tag: Optional[str] = None, sample_every: int = 1):
         self._check(self.lib.anyref_profile_config(self.h, only_tag.encode() if only_tag else None, sample_every),

@@ -151,6 +151,10 @@ int anyref_project_audio(anyref_handle* h, void* stream, const float* audio_emb,
 /* Change the inclusive [SEG] id range after creation (`seg_token_idx` kwarg, anyref.py:197-200). */
 int anyref_set_seg_range(anyref_handle* h, int lo, int hi);
 
+/* Two-stream overlap of the SAM image encoder with the LLM decode (default 1).  0 keeps the whole
+ * call on the caller's stream (used by bench.py to time kernels without a co-running stream). */
+int anyref_set_overlap(anyref_handle* h, int on);
+
 /*
  * Per-kernel timing for the measurement harness (bench.py "roofline"): when enabled, every GEMM /
  * GEMV / attention launch is bracketed by a hipEvent pair on its launch stream.  After the caller

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes into profiles/pmc_traffic.json.
+
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline
+    rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline
+    python tools/pmc_summary.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/pmc_traffic.json
+
+Units/corrections per MI355X_MICROARCH.md "HBM": the counters are in KiB; on gfx950 FETCH_SIZE reports
+exactly half of the bytes of a wide coalesced streaming read, so fetch bytes = 2 * FETCH_SIZE * 1024;
+WRITE_SIZE is exact for 16-byte streaming stores.
+"""
+import collections
+import csv
+import glob
+import json
+import sys
+
+TAGS = {  # bench.py roofline tag -> kernel-name prefix
+    "gemv_bf16": "gemv_kernel<anyref::bf16, 1, false>",
+    "gemv_bf16_swiglu": "gemv_kernel<anyref::bf16, 1, true>",
+    "gemm_bf16_128x128": "gemm_kernel<anyref::bf16, 128, 128, 64>",
+    "gemm_bf16_64x128": "gemm_kernel<anyref::bf16, 64, 128, 64>",
+    "gemm_bf16_64x64": "gemm_kernel<anyref::bf16, 64, 64, 64>",
+    "attn_bf16_hd80": "attn_kernel<anyref::bf16, 80>",
+    "attn_bf16_hd128": "attn_kernel<anyref::bf16, 128>",
+    "decode_attn_bf16": "decode_attn_kernel<anyref::bf16, 128>",
+}
+
+
+def agg(d, cname):
+    out = collections.defaultdict(lambda: [0.0, 0])
+    for f in glob.glob(d + "/*/*_counter_collection.csv"):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != cname:
+                continue
+            k = r["Kernel_Name"].split("(")[0].replace("void anyref::", "")
+            out[k][0] += float(r["Counter_Value"])
+            out[k][1] += 1
+    return out
+
+
+fe, wr = agg(sys.argv[1], "FETCH_SIZE"), agg(sys.argv[2], "WRITE_SIZE")
+res = {}
+for tag, name in TAGS.items():
+    if name in fe:
+        f, n = fe[name]
+        w, nw = wr.get(name, [0.0, 1])
+        res[tag] = {"kernel": name, "launches": n, "fetch_bytes_per_launch": 2 * f / n * 1024,
+                    "write_bytes_per_launch": w / max(nw, 1) * 1024,
+                    "hbm_bytes_per_launch": 2 * f / n * 1024 + w / max(nw, 1) * 1024,
+                    "note": "FETCH_SIZE doubled (gfx950 counts wide coalesced reads at half), KiB -> bytes"}
+json.dump(res, open(sys.argv[3], "w"), indent=1)
+print(json.dumps(res, indent=1))
