@@ -356,12 +356,12 @@ template void launch_gemm<bf16>(const GemmArgs&, hipStream_t);
 // with 16-byte loads straight to VGPRs (no LDS round trip for once-read weights:
 // cdna_hip_programming.md §5 "GEMV / M <= 16" row) and reduces across the wave.
 // ---------------------------------------------------------------------------------------------
-template <typename T, int NB, bool DUAL>
+template <typename T, int NB, bool DUAL, int XPT>  // XPT: x elements per thread held in registers, K <= 512 * XPT
 __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int b0, int nb) {
   constexpr int VN = Vec16<T>::N;
   constexpr int R = DUAL ? 1 : 2;   // output rows per wave per pass
   constexpr int RW = 2;             // weight rows streamed per pass (DUAL: gate row + up row)
-  constexpr int UNR = 4;            // 16-byte loads per row in flight per lane
+  constexpr int UNR = 4;            // 16-byte loads per row in flight per lane (8 measured slower)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* xs = reinterpret_cast<T*>(smem);  // [NB][K]
   __shared__ float red[NB][8];
@@ -397,18 +397,33 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int b0, int nb) {
                              : uint4v{0, 0, 0, 0};
     }
   };
+  // x goes FIRST into the (in-order) vector-memory queue: its wait then leaves the weight prefetch
+  // issued right behind it in flight.  Issued the other way round, the x wait also waited for the
+  // first weight chunk (measured: x staged 4-9 us into a 10-22 us kernel).
+  float xr[NB][XPT], gr[XPT];
+#pragma unroll
+  for (int i = 0; i < XPT; ++i) {  // RMSNorm gain rides in the same round trip as x
+    const int k = tid + i * 512;
+    gr[i] = (a.gain && k < K) ? a.gain[k] : 1.f;
+  }
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const float* x = a.x + (int64_t)(b0 + (b < nb ? b : 0)) * a.ldx;
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) {
+      const int k = tid + i * 512;
+      xr[b][i] = (b < nb && k < K) ? x[k] : 0.f;
+    }
+  }
   if (items > 0) load_item(0, wcur);
-
-  // stage x (with fused RMSNorm) while the first weight chunk is in flight --------------------
-  for (int b = 0; b < nb; ++b) {
-    const float* x = a.x + (int64_t)(b0 + b) * a.ldx;
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    if (b >= nb) continue;
     float scale = 1.f;
     if (a.gain) {
       float ss = 0.f;
-      for (int k = tid; k < K; k += 512) {
-        float v = x[k];
-        ss += v * v;
-      }
+#pragma unroll
+      for (int i = 0; i < XPT; ++i) ss += xr[b][i] * xr[b][i];
       ss = wave_sum(ss);
       if (lane == 0) red[b][wave] = ss;
       __syncthreads();
@@ -417,10 +432,12 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int b0, int nb) {
       for (int w = 0; w < 8; ++w) tot += red[b][w];
       scale = rsqrtf(tot / (float)K + a.eps);
     }
-    for (int k = tid; k < K; k += 512) {
-      float v = x[k] * scale;
-      if (a.gain) v *= a.gain[k];
-      xs[b * K + k] = from_f32<T>(v);
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) {
+      const int k = tid + i * 512;
+      if (k < K) {
+        xs[b * K + k] = from_f32<T>(xr[b][i] * scale * gr[i]);
+      }
     }
   }
   __syncthreads();
@@ -504,24 +521,35 @@ static void gemv_dispatch(const GemvArgs& a, int b0, int nb, hipStream_t s) {
   const size_t lds = (size_t)NB * a.K * sizeof(T);
   if (lds > 150 * 1024) throw std::runtime_error("gemv: K too large for the LDS activation stage");
   // one or two 8-wave workgroups per CU depending on the LDS the activation stage needs
-  static const int grid_mul = getenv("ANYREF_GEMV_GRID") ? atoi(getenv("ANYREF_GEMV_GRID")) : 2;  // tuning knob
-  const int grid = 256 * (lds > 76 * 1024 ? 1 : grid_mul);
-  static bool attr_set = false;  // per instantiation
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_kernel<T, NB, true>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_kernel<T, NB, false>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    attr_set = true;
-  }
-  // algorithmic bytes: every weight element once (+ the tiny activation / output vectors)
-  const double wbytes = (double)a.N * a.K * sizeof(T) * (a.W2 ? 2 : 1) + (double)nb * (a.K + a.N) * 4;
-  ProfScope prof(sizeof(T) == 2 ? (a.W2 ? "gemv_bf16_swiglu" : "gemv_bf16") : (a.W2 ? "gemv_f32_swiglu" : "gemv_f32"),
-                 2.0 * nb * a.N * (double)a.K * (a.W2 ? 2 : 1), wbytes, s);
-  if (a.W2)
-    hipLaunchKernelGGL((gemv_kernel<T, NB, true>), dim3(grid), dim3(512), lds, s, a, b0, nb);
+  // (512 workgroups measured best for N*K of 34-262 MB; 256 / 1024 / 2048 were 3-30 % slower)
+  const int grid = 256 * (lds > 76 * 1024 ? 1 : 2);
+  auto go = [&](auto xpt_tag) {
+    constexpr int XPT = decltype(xpt_tag)::value;
+    static bool attr_set = false;  // per instantiation
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_kernel<T, NB, true, XPT>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_kernel<T, NB, false, XPT>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+      attr_set = true;
+    }
+    // algorithmic bytes: every weight element once (+ the tiny activation / output vectors)
+    const double wbytes = (double)a.N * a.K * sizeof(T) * (a.W2 ? 2 : 1) + (double)nb * (a.K + a.N) * 4;
+    ProfScope prof(sizeof(T) == 2 ? (a.W2 ? "gemv_bf16_swiglu" : "gemv_bf16") : (a.W2 ? "gemv_f32_swiglu" : "gemv_f32"),
+                   2.0 * nb * a.N * (double)a.K * (a.W2 ? 2 : 1), wbytes, s);
+    if (a.W2)
+      hipLaunchKernelGGL((gemv_kernel<T, NB, true, XPT>), dim3(grid), dim3(512), lds, s, a, b0, nb);
+    else
+      hipLaunchKernelGGL((gemv_kernel<T, NB, false, XPT>), dim3(grid), dim3(512), lds, s, a, b0, nb);
+  };
+  if (a.K <= 512 * 8)
+    go(std::integral_constant<int, 8>());
+  else if (a.K <= 512 * 24)
+    go(std::integral_constant<int, 24>());
+  else if (a.K <= 512 * 32)
+    go(std::integral_constant<int, 32>());
   else
-    hipLaunchKernelGGL((gemv_kernel<T, NB, false>), dim3(grid), dim3(512), lds, s, a, b0, nb);
+    throw std::runtime_error("gemv: K > 16384 not supported");
 }
 
 template <typename T>
