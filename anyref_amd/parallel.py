@@ -34,8 +34,10 @@ def gather_results(low: torch.Tensor, nseg: torch.Tensor, ids: torch.Tensor, ids
     padded to ceil(n/world) for the collective and dropped afterwards.
     """
     world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
     per = -(-n_global // world)
+    # RCCL ("nccl" on ROCm) gathers device tensors in place; gloo (CPU tests / rehearsal) wants host tensors
+    dev = low.device
+    on_host = dist.get_backend(group) == "gloo" and dev.type != "cpu"
 
     def padrows(t):
         if t.shape[0] == per:
@@ -45,15 +47,15 @@ def gather_results(low: torch.Tensor, nseg: torch.Tensor, ids: torch.Tensor, ids
 
     outs = []
     for t in (low, nseg, ids, ids_len):
-        t = padrows(t)
+        t = padrows(t.cpu() if on_host else t)
         g = torch.empty((world * per,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
         dist.all_gather_into_tensor(g, t, group=group)
-        outs.append(g)
+        outs.append(g.to(dev) if on_host else g)
     keep = []
     for r in range(world):
         lo, hi = shard_range(n_global, r, world)
         keep += list(range(r * per, r * per + (hi - lo)))
-    keep = torch.tensor(keep, device=low.device)
+    keep = torch.tensor(keep, device=dev)
     return tuple(o.index_select(0, keep) for o in outs)
 
 
