@@ -117,6 +117,8 @@ int anyref_set_seg_range(anyref_handle* h, int lo, int hi) { GUARD(h, h->m->set_
 
 int anyref_set_overlap(anyref_handle* h, int on) { GUARD(h, h->m->set_overlap(on != 0)); }
 
+int anyref_set_graphs(anyref_handle* h, int on) { GUARD(h, h->m->set_graphs(on != 0)); }
+
 int anyref_profile_enable(anyref_handle* h, int on) {
   GUARD(h, {
     h->m->prof.on = on != 0;

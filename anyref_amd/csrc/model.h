@@ -59,6 +59,8 @@ class ModelBase {
   // two-stream overlap of the SAM encoder with the LLM decode (default on; measurement harness can
   // switch it off to time kernels without a co-running stream)
   void set_overlap(bool on) { overlap_ = on; }
+  // hipGraph replay of the greedy decode step (default on)
+  void set_graphs(bool on) { use_graphs_ = on; }
   Profiler prof;
   std::string err;
   int n_unknown = 0;
@@ -77,6 +79,7 @@ class ModelBase {
   std::map<std::string, RawTensor> raw_;
   bool finalized_ = false;
   bool overlap_ = true;
+  bool use_graphs_ = true;
 };
 
 std::unique_ptr<ModelBase> make_model(const anyref_config& cfg, int device);

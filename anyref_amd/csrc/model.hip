@@ -113,6 +113,12 @@ template <typename T>
 class Model : public ModelBase {
  public:
   Model(const anyref_config& c, int device) : ModelBase(c, device) {}
+  ~Model() override {
+    (void)hipSetDevice(device_);
+    (void)hipDeviceSynchronize();
+    for (auto& kv : decode_graphs_) (void)hipGraphExecDestroy(kv.second);
+    if (cap_stream_) (void)hipStreamDestroy(cap_stream_);
+  }
   const char* mode_name() const override { return sizeof(T) == 2 ? "bf16" : "f32"; }
   void finalize() override;
   void generate(hipStream_t s, const float* clip_images, const float* sam_images, const int64_t* input_ids,
@@ -187,6 +193,11 @@ class Model : public ModelBase {
   hipStream_t s2_ = nullptr;
   hipEvent_t ev_fork_ = nullptr, ev_sam_ = nullptr;
   bool sam_forked_ = false;
+  // One decode step is ~170 launches whose arguments never change (position and next token live on
+  // the device), so it is captured once per (batch, keep_q) and replayed as a hipGraph.
+  void decode_step_graph(hipStream_t s, int B, bool keep_q);
+  hipStream_t cap_stream_ = nullptr;
+  std::map<int, hipGraphExec_t> decode_graphs_;
   int splice_inputs(hipStream_t s, const int64_t* input_ids, const int32_t* lens, int B, int Lmax,
                     const float* extra_embeds, const int32_t* extra_slots, int n_extra,
                     std::vector<int>& slen, std::vector<int>& img_pos);
@@ -707,6 +718,35 @@ void Model<T>::fork_sam(hipStream_t s, const float* sam_images, int B) {
   sam_encoder(s2_, sam_images, B, sam_emb_);
   HIP_TRY(hipEventRecord(ev_sam_, s2_));
   sam_forked_ = true;
+}
+
+template <typename T>
+void Model<T>::decode_step_graph(hipStream_t s, int B, bool keep_q) {
+  if (!use_graphs_ || (g_prof && g_prof->on)) {  // the sampled profiler brackets kernels with events: eager
+    llm_decode_step(s, B, keep_q);
+    return;
+  }
+  const int key = B * 2 + (keep_q ? 1 : 0);
+  auto it = decode_graphs_.find(key);
+  if (it == decode_graphs_.end()) {
+    if (keep_q) ensure_q_last();
+    if (!cap_stream_) HIP_TRY(hipStreamCreateWithFlags(&cap_stream_, hipStreamNonBlocking));
+    hipGraph_t g = nullptr;
+    hipGraphExec_t ge = nullptr;
+    HIP_TRY(hipStreamBeginCapture(cap_stream_, hipStreamCaptureModeRelaxed));
+    try {
+      llm_decode_step(cap_stream_, B, keep_q);
+    } catch (...) {
+      hipStreamEndCapture(cap_stream_, &g);
+      if (g) hipGraphDestroy(g);
+      throw;
+    }
+    HIP_TRY(hipStreamEndCapture(cap_stream_, &g));
+    HIP_TRY(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    HIP_TRY(hipGraphDestroy(g));
+    it = decode_graphs_.emplace(key, ge).first;
+  }
+  HIP_TRY(hipGraphLaunch(it->second, s));
 }
 
 template <typename T>
@@ -1259,7 +1299,7 @@ void Model<T>::generate(hipStream_t s, const float* clip_images, const float* sa
       all = all && fin[b];
     }
     if (all || step == max_new_tokens - 1) break;
-    llm_decode_step(s, B, keep_q);
+    decode_step_graph(s, B, keep_q);
   }
   const int Lout = Lmax + max_new_tokens;
   std::vector<int> seg_b, seg_pos, reph(B, 0);

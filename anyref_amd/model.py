@@ -176,6 +176,10 @@ class AnyRefForCausalLM:
         """SAM encoder on a second stream under the LLM decode (default) or everything on one stream."""
         self._check(self.lib.anyref_set_overlap(self.h, int(on)), "set_overlap")
 
+    def set_graphs(self, on: bool):
+        """hipGraph replay of the greedy decode step (default) or eager launches."""
+        self._check(self.lib.anyref_set_graphs(self.h, int(on)), "set_graphs")
+
     # ---- per-kernel timing for bench.py ------------------------------------------------------
     def profile_enable(self, on: bool, only_tag: Optional[str] = None, sample_every: int = 1):
         self._check(self.lib.anyref_profile_config(self.h, only_tag.encode() if only_tag else None, sample_every),

@@ -155,6 +155,11 @@ int anyref_set_seg_range(anyref_handle* h, int lo, int hi);
  * call on the caller's stream (used by bench.py to time kernels without a co-running stream). */
 int anyref_set_overlap(anyref_handle* h, int on);
 
+/* hipGraph replay of the greedy decode step (default 1): one step is ~170 launches with fixed
+ * arguments (position / next token live on the device), captured once per batch size.  0 launches
+ * them eagerly; the per-kernel profiler below always runs eagerly. */
+int anyref_set_graphs(anyref_handle* h, int on);
+
 /*
  * Per-kernel timing for the measurement harness (bench.py "roofline"): when enabled, every GEMM /
  * GEMV / attention launch is bracketed by a hipEvent pair on its launch stream.  After the caller
