@@ -522,7 +522,8 @@ static void gemv_dispatch(const GemvArgs& a, int b0, int nb, hipStream_t s) {
   if (lds > 150 * 1024) throw std::runtime_error("gemv: K too large for the LDS activation stage");
   // one or two 8-wave workgroups per CU depending on the LDS the activation stage needs
   // (512 workgroups measured best for N*K of 34-262 MB; 256 / 1024 / 2048 were 3-30 % slower)
-  const int grid = 256 * (lds > 76 * 1024 ? 1 : 2);
+  int grid = 256 * (lds > 76 * 1024 ? 1 : 2);
+  if (const char* e = getenv("ANYREF_GEMV_GRID")) grid = atoi(e);  // EXPERIMENT
   auto go = [&](auto xpt_tag) {
     constexpr int XPT = decltype(xpt_tag)::value;
     static bool attr_set = false;  // per instantiation

@@ -214,7 +214,7 @@ void launch_build_tokens(const float* out_tokens, int n_out, const float* pred, 
 template <typename T>
 void launch_swiglu(const void* gu, int M, int F, void* out, hipStream_t s);
 // argmax over f32 rows (first index on ties) -> i64
-void launch_argmax(const float* x, int M, int N, int ldx, int64_t* out, hipStream_t s);
+void launch_argmax(const float* x, int M, int N, int ldx, int64_t* out, hipStream_t s, int* bump = nullptr);
 // ConvTranspose2d k2s2 output un-shuffle (+ LayerNorm2d + GELU): tmp f32 [n*g*g, 4*C] (col = (dy*2+dx)*C+c)
 // -> out T [n*(2g)*(2g), C] NHWC
 template <typename T>

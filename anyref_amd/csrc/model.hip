@@ -896,8 +896,7 @@ void Model<T>::llm_decode_step(hipStream_t s, int B, bool keep_q) {
   h.x = d_x_; h.ldx = H; h.gain = llm_norm_.g; h.eps = c.llm_rms_eps; h.W = lm_head_.w; h.y = l_logits_;
   h.ldy = c.llm_vocab; h.B = B; h.N = c.llm_vocab; h.K = H;
   launch_gemv<T>(h, s);
-  launch_argmax(l_logits_, B, c.llm_vocab, c.llm_vocab, next_dev_, s);
-  launch_add_i32(pos_dev_, 1, B, s);
+  launch_argmax(l_logits_, B, c.llm_vocab, c.llm_vocab, next_dev_, s, pos_dev_);  // and pos += 1
 }
 
 template <typename T>

@@ -557,39 +557,67 @@ void launch_swiglu(const void* gu, int M, int F, void* out, hipStream_t s) {
 template void launch_swiglu<float>(const void*, int, int, void*, hipStream_t);
 template void launch_swiglu<bf16>(const void*, int, int, void*, hipStream_t);
 
-// argmax, first index on ties (torch.argmax on CPU returns the first maximal index)
-__global__ void argmax_kernel(const float* __restrict__ x, int N, int ldx, int64_t* __restrict__ out) {
+// argmax, first index on ties (torch.argmax on CPU returns the first maximal index).  One 1024-thread
+// workgroup per row, 16-byte loads all issued before the first compare (the row is read once, the
+// kernel is pure latency); `bump` (optional) is a per-row counter incremented by one -- the decode
+// step's position -- so the step needs no separate increment launch.
+__device__ __forceinline__ void argmax_take(float v, int i, float& best, int& bi) {
+  if (v > best || (v == best && i < bi)) {
+    best = v;
+    bi = i;
+  }
+}
+__global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ x, int N, int ldx,
+                                                      int64_t* __restrict__ out, int* __restrict__ bump) {
+  constexpr int NT = 1024, U = 4;
   const float* row = x + (int64_t)blockIdx.x * ldx;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float best = -INFINITY;
   int bi = 0x7fffffff;
-  for (int i = threadIdx.x; i < N; i += blockDim.x) {
-    const float v = row[i];
-    if (v > best || (v == best && i < bi)) {
-      best = v;
-      bi = i;
-    }
-  }
-  __shared__ float sv[256];
-  __shared__ int si[256];
-  sv[threadIdx.x] = best;
-  si[threadIdx.x] = bi;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) {
-      const float v = sv[threadIdx.x + o];
-      const int i = si[threadIdx.x + o];
-      if (v > sv[threadIdx.x] || (v == sv[threadIdx.x] && i < si[threadIdx.x])) {
-        sv[threadIdx.x] = v;
-        si[threadIdx.x] = i;
+  if ((ldx & 3) == 0 && ((uintptr_t)x & 15) == 0) {
+    const int n4 = N >> 2;
+    for (int i0 = 0; i0 < n4; i0 += NT * U) {
+      float4 v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = i0 + u * NT + tid;
+        v[u] = i < n4 ? reinterpret_cast<const float4*>(row)[i] : float4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = (i0 + u * NT + tid) * 4;
+        argmax_take(v[u].x, i, best, bi);
+        argmax_take(v[u].y, i + 1, best, bi);
+        argmax_take(v[u].z, i + 2, best, bi);
+        argmax_take(v[u].w, i + 3, best, bi);
       }
     }
-    __syncthreads();
+    for (int i = n4 * 4 + tid; i < N; i += NT) argmax_take(row[i], i, best, bi);
+  } else {
+    for (int i = tid; i < N; i += NT) argmax_take(row[i], i, best, bi);
   }
-  if (threadIdx.x == 0) out[blockIdx.x] = si[0];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float v = __shfl_xor(best, o, 64);
+    const int i = __shfl_xor(bi, o, 64);
+    argmax_take(v, i, best, bi);
+  }
+  __shared__ float sv[NT / 64];
+  __shared__ int si[NT / 64];
+  if (lane == 0) {
+    sv[wave] = best;
+    si[wave] = bi;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < NT / 64; ++w) argmax_take(sv[w], si[w], best, bi);
+    out[blockIdx.x] = bi;
+    if (bump) bump[blockIdx.x] += 1;
+  }
 }
-void launch_argmax(const float* x, int M, int N, int ldx, int64_t* out, hipStream_t s) {
+void launch_argmax(const float* x, int M, int N, int ldx, int64_t* out, hipStream_t s, int* bump) {
   if (M <= 0) return;
-  hipLaunchKernelGGL(argmax_kernel, dim3(M), dim3(256), 0, s, x, N, ldx, out);
+  hipLaunchKernelGGL(argmax_kernel, dim3(M), dim3(1024), 0, s, x, N, ldx, out, bump);
 }
 
 // ---------------------------------------------------------------------------------------------
