@@ -61,6 +61,7 @@ SYMBOLS = {
     "anyref_set_seg_range": (_I, [_P, _I, _I]),
     "anyref_set_overlap": (_I, [_P, _I]),
     "anyref_set_graphs": (_I, [_P, _I]),
+    "anyref_set_persistent_decode": (_I, [_P, _I]),
     "anyref_profile_enable": (_I, [_P, _I]),
     "anyref_profile_config": (_I, [_P, C.c_char_p, _I]),
     "anyref_profile_collect": (_I, [_P]),

@@ -119,6 +119,8 @@ int anyref_set_overlap(anyref_handle* h, int on) { GUARD(h, h->m->set_overlap(on
 
 int anyref_set_graphs(anyref_handle* h, int on) { GUARD(h, h->m->set_graphs(on != 0)); }
 
+int anyref_set_persistent_decode(anyref_handle* h, int on) { GUARD(h, h->m->set_persistent_decode(on != 0)); }
+
 int anyref_profile_enable(anyref_handle* h, int on) {
   GUARD(h, {
     h->m->prof.on = on != 0;

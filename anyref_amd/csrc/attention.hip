@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <type_traits>
 
+#include "decode_attn.h"
 #include "kernels.h"
 
 namespace anyref {
@@ -381,136 +382,13 @@ void launch_attention(const AttnArgs& a, hipStream_t s) {
 template void launch_attention<float>(const AttnArgs&, hipStream_t);
 template void launch_attention<bf16>(const AttnArgs&, hipStream_t);
 
-// ---------------------------------------------------------------------------------------------
-// Decode-step attention (one query per sequence), fused with RoPE + KV-cache append.  Latency
-// bound: one 256-thread workgroup per (head, sequence); LPK = hd/VEC lanes share one key (16-byte
-// loads straight from the cache), KPI = 256/LPK keys per sweep.
-// ---------------------------------------------------------------------------------------------
 template <typename T, int HD>
 __global__ __launch_bounds__(512) void decode_attn_kernel(const float* __restrict__ qkv, const int* __restrict__ pos,
                                                           const float* __restrict__ cs_tab, T* __restrict__ kc,
                                                           T* __restrict__ vc, int maxS, int H, float scale,
                                                           float* __restrict__ out, T* __restrict__ q_keep) {
-  constexpr int NT = 512, NWV = NT / 64, UN = 4;
-  constexpr int VEC = Vec16<T>::N, LPK = HD / VEC, KPI = NT / LPK, HALF = HD / 2;
-  static_assert(LPK <= 64 && (LPK & (LPK - 1)) == 0, "lanes per key must be a power of two within a wave");
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* q_s = sm;                 // [HD] rotated, T-rounded, pre-scaled query
-  float* k_s = q_s + HD;           // [HD] this step's key (as stored in the cache)
-  float* v_s = k_s + HD;           // [HD]
-  float* part = v_s + HD;          // [KPI][HD]
-  float* red = part + KPI * HD;    // [2*NWV]
-  float* sc = red + 2 * NWV;       // [maxS] scores / probabilities
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int h = blockIdx.x, b = blockIdx.y;
-  const int p = pos[b], n = p + 1;
-  const float* row = qkv + (int64_t)b * 3 * H * HD;
-  const int64_t cbase = ((int64_t)b * maxS * H + h) * HD;   // + j*H*HD for key j
-
-  if (tid < HALF) {
-    const int d = tid;
-    const float cs = cs_tab[((int64_t)p * 2) * HALF + d], sn = cs_tab[((int64_t)p * 2 + 1) * HALF + d];
-    const float q1 = row[h * HD + d], q2 = row[h * HD + d + HALF];
-    const float k1 = row[(H + h) * HD + d], k2 = row[(H + h) * HD + d + HALF];
-    const T qa = from_f32<T>(q1 * cs - q2 * sn), qb = from_f32<T>(q2 * cs + q1 * sn);
-    const T ka = from_f32<T>(k1 * cs - k2 * sn), kb = from_f32<T>(k2 * cs + k1 * sn);
-    const T va = from_f32<T>(row[(2 * H + h) * HD + d]), vb = from_f32<T>(row[(2 * H + h) * HD + d + HALF]);
-    const int64_t co = cbase + (int64_t)p * H * HD;
-    kc[co + d] = ka; kc[co + d + HALF] = kb;
-    vc[co + d] = va; vc[co + d + HALF] = vb;
-    if (q_keep) { q_keep[co + d] = qa; q_keep[co + d + HALF] = qb; }
-    q_s[d] = to_f32<T>(qa) * scale; q_s[d + HALF] = to_f32<T>(qb) * scale;
-    k_s[d] = to_f32<T>(ka); k_s[d + HALF] = to_f32<T>(kb);
-    v_s[d] = to_f32<T>(va); v_s[d + HALF] = to_f32<T>(vb);
-  }
-  __syncthreads();
-  const int sub = tid % LPK, slice = tid / LPK;
-  float qf[VEC];
-#pragma unroll
-  for (int i = 0; i < VEC; ++i) qf[i] = q_s[sub * VEC + i];
-  // ---- scores: UN keys per thread in flight (the loop is latency-, not bandwidth-bound) ----
-  for (int j0 = 0; j0 < n; j0 += KPI * UN) {
-    uint4v kv[UN];
-#pragma unroll
-    for (int u = 0; u < UN; ++u) {
-      const int j = j0 + u * KPI + slice;
-      kv[u] = j < p ? *reinterpret_cast<const uint4v*>(kc + cbase + (int64_t)j * H * HD + sub * VEC)
-                    : uint4v{0, 0, 0, 0};
-    }
-#pragma unroll
-    for (int u = 0; u < UN; ++u) {
-      const int j = j0 + u * KPI + slice;
-      float kf[VEC];
-      Vec16<T>::unpack(kv[u], kf);
-      if (j == p) {
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) kf[i] = k_s[sub * VEC + i];
-      }
-      float dot = 0.f;
-#pragma unroll
-      for (int i = 0; i < VEC; ++i) dot = fmaf(qf[i], kf[i], dot);
-#pragma unroll
-      for (int o = 1; o < LPK; o <<= 1) dot += __shfl_xor(dot, o, 64);
-      if (sub == 0 && j < n) sc[j] = dot;
-    }
-  }
-  __syncthreads();
-  // ---- softmax over sc[0,n) ----
-  float mx = -INFINITY;
-  for (int j = tid; j < n; j += NT) mx = fmaxf(mx, sc[j]);
-  mx = wave_max(mx);
-  if (lane == 0) red[wave] = mx;
-  __syncthreads();
-  mx = red[0];
-#pragma unroll
-  for (int w = 1; w < NWV; ++w) mx = fmaxf(mx, red[w]);
-  float sum = 0.f;
-  for (int j = tid; j < n; j += NT) {
-    const float e = expf(sc[j] - mx);
-    sc[j] = e;
-    sum += e;
-  }
-  sum = wave_sum(sum);
-  if (lane == 0) red[NWV + wave] = sum;
-  __syncthreads();
-  sum = 0.f;
-#pragma unroll
-  for (int w = 0; w < NWV; ++w) sum += red[NWV + w];
-  // ---- O = P V ----
-  float acc[VEC];
-#pragma unroll
-  for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
-  for (int j0 = 0; j0 < n; j0 += KPI * UN) {
-    uint4v vv[UN];
-#pragma unroll
-    for (int u = 0; u < UN; ++u) {
-      const int j = j0 + u * KPI + slice;
-      vv[u] = j < p ? *reinterpret_cast<const uint4v*>(vc + cbase + (int64_t)j * H * HD + sub * VEC)
-                    : uint4v{0, 0, 0, 0};
-    }
-#pragma unroll
-    for (int u = 0; u < UN; ++u) {
-      const int j = j0 + u * KPI + slice;
-      float vf[VEC];
-      Vec16<T>::unpack(vv[u], vf);
-      if (j == p) {
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) vf[i] = v_s[sub * VEC + i];
-      }
-      const float pj = j < n ? sc[j] : 0.f;
-#pragma unroll
-      for (int i = 0; i < VEC; ++i) acc[i] = fmaf(pj, vf[i], acc[i]);
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < VEC; ++i) part[slice * HD + sub * VEC + i] = acc[i];
-  __syncthreads();
-  if (tid < HD) {
-    float o = 0.f;
-#pragma unroll
-    for (int sI = 0; sI < KPI; ++sI) o += part[sI * HD + tid];
-    out[((int64_t)b * H + h) * HD + tid] = o / sum;
-  }
+  decode_attn_body<T, HD, false>(qkv, pos, cs_tab, kc, vc, maxS, H, scale, out, q_keep, blockIdx.x, blockIdx.y, sm);
 }
 
 template <typename T>
@@ -519,8 +397,7 @@ bool launch_decode_attn(const float* qkv, int B, int H, int hd, const int* pos, 
   constexpr int VEC = Vec16<T>::N;
   auto go = [&](auto tagHD) {
     constexpr int HD = decltype(tagHD)::value;
-    constexpr int KPI = 512 / (HD / VEC);
-    const size_t lds = sizeof(float) * (3 * HD + KPI * HD + 16 + maxS + KPI * 4);
+    const size_t lds = decode_attn_lds<T, HD>(maxS);
     const double kvbytes = 2.0 * B * H * HD * sizeof(T) * (maxS / 2);  // nominal: half-full cache
     ProfScope prof(sizeof(T) == 2 ? "decode_attn_bf16" : "decode_attn_f32", 0.0, kvbytes, s);
     hipLaunchKernelGGL((decode_attn_kernel<T, HD>), dim3(H, B), dim3(512), lds, s, qkv, pos, cs_tab,

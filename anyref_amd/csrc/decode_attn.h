@@ -1,0 +1,173 @@
+// Decode-step attention body, shared by decode_attn_kernel (attention.hip) and the persistent
+// decode-step kernel (decode.hip).
+#pragma once
+#include "common.h"
+
+namespace anyref {
+
+// Loads / stores of vectors that another workgroup of the SAME launch produced or will consume:
+// agent-scope relaxed atomics (global_load/store ... sc1) go past the per-XCD L2, so no cache
+// write-back / invalidate is needed around the grid barrier of the persistent kernel.
+template <bool COH>
+__device__ __forceinline__ float ld_x(const float* p) {
+  if (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return *p;
+}
+// The coherent store is an atomic exchange WITH return: a plain write-through store is acknowledged
+// by the issuing XCD's L2 before it is visible at the memory side, so under a saturated fabric the
+// barrier arrival (another address, another channel) could overtake it and a reader on another XCD
+// would see the old value (observed: wrong tokens whenever another stream or a graph replay changed
+// the timing).  The returning atomic completes at the coherence point; s_waitcnt vmcnt(0) in
+// grid_arrive then really means "visible".
+template <bool COH>
+__device__ __forceinline__ void st_x(float* p, float v) {
+  if (COH) {
+    const float old = __hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("" ::"v"(old));
+  } else {
+    *p = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Decode-step attention (one query per sequence), fused with RoPE + KV-cache append.  Latency
+// bound: one 256-thread workgroup per (head, sequence); LPK = hd/VEC lanes share one key (16-byte
+// loads straight from the cache), KPI = 256/LPK keys per sweep.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int HD, bool COH>
+__device__ __forceinline__ void decode_attn_body(const float* __restrict__ qkv, const int* __restrict__ pos,
+                                                 const float* __restrict__ cs_tab, T* __restrict__ kc,
+                                                 T* __restrict__ vc, int maxS, int H, float scale,
+                                                 float* __restrict__ out, T* __restrict__ q_keep, int h, int b,
+                                                 float* sm) {
+  constexpr int NT = 512, NWV = NT / 64, UN = 4;
+  constexpr int VEC = Vec16<T>::N, LPK = HD / VEC, KPI = NT / LPK, HALF = HD / 2;
+  static_assert(LPK <= 64 && (LPK & (LPK - 1)) == 0, "lanes per key must be a power of two within a wave");
+  float* q_s = sm;                 // [HD] rotated, T-rounded, pre-scaled query
+  float* k_s = q_s + HD;           // [HD] this step's key (as stored in the cache)
+  float* v_s = k_s + HD;           // [HD]
+  float* part = v_s + HD;          // [KPI][HD]
+  float* red = part + KPI * HD;    // [2*NWV]
+  float* sc = red + 2 * NWV;       // [maxS] scores / probabilities
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int p = pos[b], n = p + 1;
+  const float* row = qkv + (int64_t)b * 3 * H * HD;
+  const int64_t cbase = ((int64_t)b * maxS * H + h) * HD;   // + j*H*HD for key j
+
+  if (tid < HALF) {
+    const int d = tid;
+    const float cs = cs_tab[((int64_t)p * 2) * HALF + d], sn = cs_tab[((int64_t)p * 2 + 1) * HALF + d];
+    const float q1 = ld_x<COH>(&row[h * HD + d]), q2 = ld_x<COH>(&row[h * HD + d + HALF]);
+    const float k1 = ld_x<COH>(&row[(H + h) * HD + d]), k2 = ld_x<COH>(&row[(H + h) * HD + d + HALF]);
+    const T qa = from_f32<T>(q1 * cs - q2 * sn), qb = from_f32<T>(q2 * cs + q1 * sn);
+    const T ka = from_f32<T>(k1 * cs - k2 * sn), kb = from_f32<T>(k2 * cs + k1 * sn);
+    const T va = from_f32<T>(ld_x<COH>(&row[(2 * H + h) * HD + d]));
+    const T vb = from_f32<T>(ld_x<COH>(&row[(2 * H + h) * HD + d + HALF]));
+    const int64_t co = cbase + (int64_t)p * H * HD;
+    kc[co + d] = ka; kc[co + d + HALF] = kb;
+    vc[co + d] = va; vc[co + d + HALF] = vb;
+    if (q_keep) { q_keep[co + d] = qa; q_keep[co + d + HALF] = qb; }
+    q_s[d] = to_f32<T>(qa) * scale; q_s[d + HALF] = to_f32<T>(qb) * scale;
+    k_s[d] = to_f32<T>(ka); k_s[d + HALF] = to_f32<T>(kb);
+    v_s[d] = to_f32<T>(va); v_s[d + HALF] = to_f32<T>(vb);
+  }
+  __syncthreads();
+  const int sub = tid % LPK, slice = tid / LPK;
+  float qf[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) qf[i] = q_s[sub * VEC + i];
+  // ---- scores: UN keys per thread in flight (the loop is latency-, not bandwidth-bound) ----
+  for (int j0 = 0; j0 < n; j0 += KPI * UN) {
+    uint4v kv[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int j = j0 + u * KPI + slice;
+      kv[u] = j < p ? *reinterpret_cast<const uint4v*>(kc + cbase + (int64_t)j * H * HD + sub * VEC)
+                    : uint4v{0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int j = j0 + u * KPI + slice;
+      float kf[VEC];
+      Vec16<T>::unpack(kv[u], kf);
+      if (j == p) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) kf[i] = k_s[sub * VEC + i];
+      }
+      float dot = 0.f;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) dot = fmaf(qf[i], kf[i], dot);
+#pragma unroll
+      for (int o = 1; o < LPK; o <<= 1) dot += __shfl_xor(dot, o, 64);
+      if (sub == 0 && j < n) sc[j] = dot;
+    }
+  }
+  __syncthreads();
+  // ---- softmax over sc[0,n) ----
+  float mx = -INFINITY;
+  for (int j = tid; j < n; j += NT) mx = fmaxf(mx, sc[j]);
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = red[0];
+#pragma unroll
+  for (int w = 1; w < NWV; ++w) mx = fmaxf(mx, red[w]);
+  float sum = 0.f;
+  for (int j = tid; j < n; j += NT) {
+    const float e = expf(sc[j] - mx);
+    sc[j] = e;
+    sum += e;
+  }
+  sum = wave_sum(sum);
+  if (lane == 0) red[NWV + wave] = sum;
+  __syncthreads();
+  sum = 0.f;
+#pragma unroll
+  for (int w = 0; w < NWV; ++w) sum += red[NWV + w];
+  // ---- O = P V ----
+  float acc[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+  for (int j0 = 0; j0 < n; j0 += KPI * UN) {
+    uint4v vv[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int j = j0 + u * KPI + slice;
+      vv[u] = j < p ? *reinterpret_cast<const uint4v*>(vc + cbase + (int64_t)j * H * HD + sub * VEC)
+                    : uint4v{0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int j = j0 + u * KPI + slice;
+      float vf[VEC];
+      Vec16<T>::unpack(vv[u], vf);
+      if (j == p) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) vf[i] = v_s[sub * VEC + i];
+      }
+      const float pj = j < n ? sc[j] : 0.f;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[i] = fmaf(pj, vf[i], acc[i]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) part[slice * HD + sub * VEC + i] = acc[i];
+  __syncthreads();
+  if (tid < HD) {
+    float o = 0.f;
+#pragma unroll
+    for (int sI = 0; sI < KPI; ++sI) o += part[sI * HD + tid];
+    st_x<COH>(&out[((int64_t)b * H + h) * HD + tid], o / sum);
+  }
+}
+
+// dynamic LDS (bytes) decode_attn_body needs
+template <typename T, int HD>
+inline size_t decode_attn_lds(int maxS) {
+  constexpr int KPI = 512 / (HD / Vec16<T>::N);
+  return sizeof(float) * (size_t)(3 * HD + KPI * HD + 16 + maxS + KPI * 4);
+}
+
+}  // namespace anyref
+
+

@@ -233,6 +233,8 @@ class Model : public ModelBase {
   float *l_x_ = nullptr, *hidden_all_ = nullptr, *l_logits_ = nullptr, *l_xlast_ = nullptr;
   T *l_h_ = nullptr, *l_qkv_ = nullptr, *l_q_ = nullptr, *l_att_ = nullptr, *l_gu_ = nullptr, *l_act_ = nullptr;
   float *d_x_ = nullptr, *d_qkv_ = nullptr, *d_att_ = nullptr, *d_act_ = nullptr;
+  DecodeLayerPtrs* llm_dec_ptrs_ = nullptr;  // device array for the persistent decode kernel
+  unsigned* dec_sync_ = nullptr;
   T* d_q_ = nullptr;
   int64_t *ids_dev_ = nullptr, *next_dev_ = nullptr;
   int *lens_dev_ = nullptr, *slen_dev_ = nullptr, *pos_dev_ = nullptr, *kvlen_dev_ = nullptr, *rowmap_dev_ = nullptr,
@@ -474,6 +476,19 @@ void Model<T>::finalize() {
     d_qkv_ = talloc<float>((size_t)MB * 3 * H);
     d_att_ = talloc<float>((size_t)MB * H);
     d_act_ = talloc<float>((size_t)MB * F);
+    dec_sync_ = reinterpret_cast<unsigned*>(dalloc(decode_sync_bytes()));
+    HIP_TRY(hipMemset(dec_sync_, 0, decode_sync_bytes()));
+    {  // per-layer pointer table of the persistent decode kernel
+      const int nl = c.llm_layers;
+      std::vector<DecodeLayerPtrs> hp(nl);
+      for (int i = 0; i < nl; ++i) {
+        LlmLayer& L = llm_layers_[i];
+        hp[i] = DecodeLayerPtrs{L.in_norm.g, L.post_norm.g, L.qkv.w, L.o.w, L.gate_w, L.up_w, L.down.w,
+                                kcache_ + cache_layer_stride_ * i, vcache_ + cache_layer_stride_ * i};
+      }
+      llm_dec_ptrs_ = reinterpret_cast<DecodeLayerPtrs*>(dalloc(sizeof(DecodeLayerPtrs) * nl));
+      HIP_TRY(hipMemcpy(llm_dec_ptrs_, hp.data(), sizeof(DecodeLayerPtrs) * nl, hipMemcpyHostToDevice));
+    }
     d_q_ = talloc<T>((size_t)MB * H);
     ids_dev_ = talloc<int64_t>((size_t)MB * S);
     next_dev_ = talloc<int64_t>(MB);
@@ -726,7 +741,7 @@ void Model<T>::decode_step_graph(hipStream_t s, int B, bool keep_q) {
     llm_decode_step(s, B, keep_q);
     return;
   }
-  const int key = B * 2 + (keep_q ? 1 : 0);
+  const int key = (B * 2 + (keep_q ? 1 : 0)) * 2 + (persistent_decode_ ? 1 : 0);
   auto it = decode_graphs_.find(key);
   if (it == decode_graphs_.end()) {
     if (keep_q) ensure_q_last();
@@ -855,7 +870,16 @@ void Model<T>::llm_decode_step(hipStream_t s, int B, bool keep_q) {
   const int H = c.llm_dim, F = c.llm_mlp, nh = c.llm_heads, hd = H / nh, S = c.llm_max_seq, nl = c.llm_layers;
   launch_embed_rows(next_dev_, B, emb_table_, sizeof(T) == 2, H, d_x_, s);
   launch_decode_index(pos_dev_, B, S, rowmap_dev_, kvlen_dev_, s);
-  for (int i = 0; i < nl; ++i) {
+  bool layers_done = false;
+  if (persistent_decode_) {
+    DecodeStepArgs da;
+    da.layers = llm_dec_ptrs_; da.nl = nl; da.B = B; da.H = H; da.F = F; da.nh = nh; da.maxS = S;
+    da.eps = c.llm_rms_eps; da.scale = 1.f / sqrtf((float)hd);
+    da.x = d_x_; da.qkv = d_qkv_; da.att = d_att_; da.act = d_act_;
+    da.pos = pos_dev_; da.rope = rope_tab_; da.q_keep = keep_q ? q_last_ : nullptr; da.sync = dec_sync_;
+    layers_done = launch_decode_layers<T>(da, s);
+  }
+  for (int i = 0; i < nl && !layers_done; ++i) {
     LlmLayer& L = llm_layers_[i];
     T* kc = kcache_ + cache_layer_stride_ * i;
     T* vc = vcache_ + cache_layer_stride_ * i;

@@ -180,6 +180,10 @@ class AnyRefForCausalLM:
         """hipGraph replay of the greedy decode step (default) or eager launches."""
         self._check(self.lib.anyref_set_graphs(self.h, int(on)), "set_graphs")
 
+    def set_persistent_decode(self, on: bool):
+        """One persistent kernel per decode step, or (default) one launch per GEMV / attention."""
+        self._check(self.lib.anyref_set_persistent_decode(self.h, int(on)), "set_persistent_decode")
+
     # ---- per-kernel timing for bench.py ------------------------------------------------------
     def profile_enable(self, on: bool, only_tag: Optional[str] = None, sample_every: int = 1):
         self._check(self.lib.anyref_profile_config(self.h, only_tag.encode() if only_tag else None, sample_every),

@@ -160,6 +160,13 @@ int anyref_set_overlap(anyref_handle* h, int on);
  * them eagerly; the per-kernel profiler below always runs eagerly. */
 int anyref_set_graphs(anyref_handle* h, int on);
 
+/* Persistent decode kernel (default 0): all LLM layers of one greedy step run in a single launch
+ * whose workgroups meet at grid barriers (csrc/decode.hip), bit-identical to the op-by-op path.
+ * Kept as a measured alternative: on MI355X it is ~8 % slower per step than one launch per GEMV /
+ * attention.  Shapes it does not cover (batch > 2 per call, head dim other than
+ * 64/128) always use the op-by-op path. */
+int anyref_set_persistent_decode(anyref_handle* h, int on);
+
 /*
  * Per-kernel timing for the measurement harness (bench.py "roofline"): when enabled, every GEMM /
  * GEMV / attention launch is bracketed by a hipEvent pair on its launch stream.  After the caller
