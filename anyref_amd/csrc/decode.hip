@@ -434,6 +434,10 @@ bool launch_decode_layers(const DecodeStepArgs& a, hipStream_t s) {
       int g = cus * (per_cu < 2 ? per_cu : 2);
       g -= g % 8;
       grid = g >= 8 ? g : -1;
+      // an instantiation that spilled to scratch is refused (see the note above the kernel)
+      hipFuncAttributes fa;
+      HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kern)));
+      if (fa.localSizeBytes > 0) grid = -1;
       grid_lds = lds;
     }
     if (grid < 0) return false;

@@ -56,13 +56,21 @@ __device__ __forceinline__ void static_for(std::integer_sequence<int, Is...>, F&
   (f(std::integral_constant<int, Is>{}), ...);
 }
 
-template <typename T>
+// ACT and VEC are compile-time: the epilogue is fully unrolled over the wave's MI x NI fragments, and with
+// a runtime activation switch + both store paths inlined per fragment the 256 x 256 kernel was 45 k lines
+// of assembly whose (mostly skipped) epilogue cost ~20 us of a 65 us GEMM in instruction fetch.
+template <int ACT>
+__device__ __forceinline__ float act_ct(float v) {
+  if constexpr (ACT == ACT_NONE) return v;
+  else return apply_act(v, ACT);
+}
+
+template <typename T, int ACT, bool VEC>
 __device__ __forceinline__ void epi_store4(const GemmArgs& a, const float* bias, const float* resid, float* Cf, T* Ct,
-                                           bool vec, int dm, int n, float v0, float v1, float v2, float v3) {
-  if (vec) {  // N % 4 == 0: the four columns are all valid, rows are 16-byte aligned
-    float4v v = float4v{v0, v1, v2, v3};
+                                           int dm, int n, float4v v) {
+  if constexpr (VEC) {  // N % 4 == 0: the four columns are all valid, rows are 16-byte aligned
     if (bias) v += *reinterpret_cast<const float4v*>(bias + n);
-    v = float4v{apply_act(v[0], a.act), apply_act(v[1], a.act), apply_act(v[2], a.act), apply_act(v[3], a.act)};
+    v = float4v{act_ct<ACT>(v[0]), act_ct<ACT>(v[1]), act_ct<ACT>(v[2]), act_ct<ACT>(v[3])};
     if (resid) v += *reinterpret_cast<const float4v*>(resid + (int64_t)dm * a.ldr + n);
     if (a.c_f32) {
       *reinterpret_cast<float4v*>(Cf + (int64_t)dm * a.ldc + n) = v;
@@ -73,51 +81,66 @@ __device__ __forceinline__ void epi_store4(const GemmArgs& a, const float* bias,
     } else {
       *reinterpret_cast<float4v*>(Ct + (int64_t)dm * a.ldc + n) = v;
     }
-    return;
+  } else {  // scalar tail path (N not a multiple of 4 / unaligned)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (n + r < a.N) {
+        float x = v[r];
+        if (bias) x += bias[n + r];
+        x = act_ct<ACT>(x);
+        if (resid) x += resid[(int64_t)dm * a.ldr + n + r];
+        if (a.c_f32)
+          Cf[(int64_t)dm * a.ldc + n + r] = x;
+        else
+          Ct[(int64_t)dm * a.ldc + n + r] = from_f32<T>(x);
+      }
+    }
   }
-  // scalar tail path (N not a multiple of 4 / unaligned)
-  const float vs0 = v0, vs1 = v1, vs2 = v2, vs3 = v3;
-#define ANYREF_PUT(r, x0)                                         \
-  if (n + r < a.N) {                                              \
-    float x = x0;                                                 \
-    if (bias) x += bias[n + r];                                   \
-    x = apply_act(x, a.act);                                      \
-    if (resid) x += resid[(int64_t)dm * a.ldr + n + r];           \
-    if (a.c_f32)                                                  \
-      Cf[(int64_t)dm * a.ldc + n + r] = x;                        \
-    else                                                          \
-      Ct[(int64_t)dm * a.ldc + n + r] = from_f32<T>(x);           \
-  }
-  ANYREF_PUT(0, vs0)
-  ANYREF_PUT(1, vs1)
-  ANYREF_PUT(2, vs2)
-  ANYREF_PUT(3, vs3)
-#undef ANYREF_PUT
 }
 
-template <typename T, int BM, int BN>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, float4v (&acc)[BM / 32][BN / 32], int m0, int n0, int z,
-                                              int lane, int wr, int wc) {
-  constexpr int MI = BM / 32, NI = BN / 32;
+template <typename T, int MI, int NI, int ACT, bool VEC>
+__device__ __forceinline__ void gemm_epilogue_ct(const GemmArgs& a, float4v (&acc)[MI][NI], int mrow0, int ncol0, int z,
+                                                 int lane) {
   const float* bias = a.bias ? a.bias + (int64_t)z * a.sBias : nullptr;
   const float* resid = a.resid ? a.resid + (int64_t)z * a.sR : nullptr;
   float* Cf = reinterpret_cast<float*>(a.C) + (int64_t)z * a.sC;
   T* Ct = reinterpret_cast<T*>(a.C) + (int64_t)z * a.sC;
-  const bool vec = a.vec_ok != 0;
   // NB: every acc index must stay a compile-time constant (full unroll, no `continue`): a runtime-indexed
   // accumulator array is demoted to scratch memory for the WHOLE kernel (guide rule 20; measured 3x slower).
   int dms[MI];
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
-    const int m = m0 + wr * (BM / 2) + i * 16 + (lane & 15);
+    const int m = mrow0 + i * 16 + (lane & 15);
     dms[i] = m < a.M ? (a.row_map ? a.row_map[m] : m) : -1;
   }
   static_for(std::make_integer_sequence<int, MI * NI>{}, [&](auto ij) {
     constexpr int i = decltype(ij)::value / NI, j = decltype(ij)::value % NI;
-    const int n = n0 + wc * (BN / 2) + j * 16 + 4 * (lane >> 4);
-    const float4v v = acc[i][j] * a.alpha;
-    if (dms[i] >= 0 && n < a.N) epi_store4<T>(a, bias, resid, Cf, Ct, vec, dms[i], n, v[0], v[1], v[2], v[3]);
+    const int n = ncol0 + j * 16 + 4 * (lane >> 4);
+    if (dms[i] >= 0 && n < a.N) epi_store4<T, ACT, VEC>(a, bias, resid, Cf, Ct, dms[i], n, acc[i][j] * a.alpha);
   });
+}
+
+// mrow0 / ncol0: first output row / column of this WAVE's sub-tile (MI x NI fragments of 16 x 16)
+template <typename T, int MI, int NI>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, float4v (&acc)[MI][NI], int mrow0, int ncol0, int z,
+                                              int lane) {
+  if (a.vec_ok) {
+    switch (a.act) {
+      case ACT_NONE: gemm_epilogue_ct<T, MI, NI, ACT_NONE, true>(a, acc, mrow0, ncol0, z, lane); break;
+      case ACT_RELU: gemm_epilogue_ct<T, MI, NI, ACT_RELU, true>(a, acc, mrow0, ncol0, z, lane); break;
+      case ACT_GELU: gemm_epilogue_ct<T, MI, NI, ACT_GELU, true>(a, acc, mrow0, ncol0, z, lane); break;
+      case ACT_QUICK_GELU: gemm_epilogue_ct<T, MI, NI, ACT_QUICK_GELU, true>(a, acc, mrow0, ncol0, z, lane); break;
+      default: gemm_epilogue_ct<T, MI, NI, ACT_SILU, true>(a, acc, mrow0, ncol0, z, lane); break;
+    }
+  } else {
+    switch (a.act) {
+      case ACT_NONE: gemm_epilogue_ct<T, MI, NI, ACT_NONE, false>(a, acc, mrow0, ncol0, z, lane); break;
+      case ACT_RELU: gemm_epilogue_ct<T, MI, NI, ACT_RELU, false>(a, acc, mrow0, ncol0, z, lane); break;
+      case ACT_GELU: gemm_epilogue_ct<T, MI, NI, ACT_GELU, false>(a, acc, mrow0, ncol0, z, lane); break;
+      case ACT_QUICK_GELU: gemm_epilogue_ct<T, MI, NI, ACT_QUICK_GELU, false>(a, acc, mrow0, ncol0, z, lane); break;
+      default: gemm_epilogue_ct<T, MI, NI, ACT_SILU, false>(a, acc, mrow0, ncol0, z, lane); break;
+    }
+  }
 }
 
 template <typename T, int BM, int BN, int BK>
@@ -208,7 +231,134 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a) {  // 2 waves/
     __syncthreads();
   }
 
-  gemm_epilogue<T, BM, BN>(a, acc, m0, n0, z, lane, wr, wc);
+  gemm_epilogue<T, MI, NI>(a, acc, m0 + wr * (BM / 2), n0 + wc * (BN / 2), z, lane);
+}
+
+// ---------------------------------------------------------------------------------------------
+// bf16 GEMM, LDS-DMA staging (perf mode).  BM x BN x 64 tile, WM x WN waves; both operand tiles go
+// global -> LDS with global_load_lds (16 bytes per lane, no VGPR round trip) into TWO stage buffers:
+// tile t+1 is requested before tile t is multiplied and is only waited for after, so one raw barrier
+// per K tile is the whole synchronisation.  Against the register-staged kernel above (2 barriers per
+// tile, one tile of lead) this is 1.2-1.6x on the SAM / prefill / CLIP shapes (scratch/lab/gemm_lab.hip);
+// the 256 x 256 tile doubles the FLOPs per L2 byte, which is what bounded the 128^2 kernel (~25 % of
+// the MFMA peak = ~9 TB/s of L2 reads).
+//
+// LDS image: rows of 64 bf16 = 128 bytes, 16-byte chunk c of row r stored at chunk c ^ ((r >> 1) & 7).
+// An LDS-DMA instruction writes lane-linearly (base + 16 * lane = 8 rows), so the permutation is applied
+// to the SOURCE address each lane fetches and again on the fragment reads (cdna_hip_programming.md
+// rule 21); with it the 16 rows a quarter-wave reads for one MFMA operand hit 16 different 16-byte
+// slots of the 256-byte bank row.
+// ---------------------------------------------------------------------------------------------
+typedef const __attribute__((address_space(1))) void* gas_ptr;
+typedef __attribute__((address_space(3))) void* las_ptr;
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs a) {
+  using T = bf16;
+  constexpr int BK = 64, NW = WM * WN;
+  constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 16, NI = TN / 16;
+  constexpr int ROWB = BK * 2;             // bytes per tile row
+  constexpr int TILEB = (BM + BN) * ROWB;  // one stage
+  constexpr int RA = BM / (NW * 8), RW = BN / (NW * 8);  // LDS-DMA rounds (8 rows per wave instruction)
+  static_assert(BM % (NW * 8) == 0 && BN % (NW * 8) == 0, "tile rows must split over the waves");
+  extern __shared__ __attribute__((aligned(1024))) char smem[];  // the ONLY LDS object (rule: one array)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave / WN, wc = wave % WN;
+  const int tiles_m = cdiv(a.M, BM), tiles_n = cdiv(a.N, BN), nwg = tiles_m * tiles_n;
+  int id = blockIdx.x;
+  if (a.order & 1) {
+    const int q = nwg / 8, r = nwg % 8, xcd = id % 8;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + id / 8;
+  }
+  const int m0 = ((a.order & 2) ? id % tiles_m : id / tiles_n) * BM;
+  const int n0 = ((a.order & 2) ? id / tiles_m : id % tiles_n) * BN;
+  const int z = blockIdx.z;
+  const T* __restrict__ A = reinterpret_cast<const T*>(a.A) + (int64_t)z * a.sA;
+  const T* __restrict__ W = reinterpret_cast<const T*>(a.W) + (int64_t)z * a.sW;
+
+  float4v acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
+
+  // rows past M / N fetch the last valid row (never stored); K is a multiple of 64 (launcher)
+  const int srow = lane >> 3, sp = lane & 7;
+  const T* asrc[RA];
+  const T* wsrc[RW];
+#pragma unroll
+  for (int r = 0; r < RA; ++r) {
+    const int row = (r * NW + wave) * 8 + srow;
+    int gm = m0 + row;
+    gm = gm < a.M ? gm : a.M - 1;
+    asrc[r] = A + (int64_t)gm * a.lda + ((sp ^ ((row >> 1) & 7)) << 3);
+  }
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    const int row = (r * NW + wave) * 8 + srow;
+    int gn = n0 + row;
+    gn = gn < a.N ? gn : a.N - 1;
+    wsrc[r] = W + (int64_t)gn * a.ldw + ((sp ^ ((row >> 1) & 7)) << 3);
+  }
+  // The stage index is a compile-time constant (loop unrolled by two below): with a runtime index hipcc
+  // cannot tell the DMA destination from the buffer being read and puts s_waitcnt vmcnt(0) in front of the
+  // first ds_read of every tile, which serialises the prefetch (seen in the .s; -40 % on 256^2).
+  auto stage = [&](auto buf_c, int t) {
+    constexpr int buf = decltype(buf_c)::value;
+    char* base = smem + buf * TILEB;
+#pragma unroll
+    for (int r = 0; r < RA; ++r)
+      __builtin_amdgcn_global_load_lds((gas_ptr)(asrc[r] + t * BK), (las_ptr)(base + (r * NW + wave) * 8 * ROWB), 16, 0,
+                                       0);
+#pragma unroll
+    for (int r = 0; r < RW; ++r)
+      __builtin_amdgcn_global_load_lds((gas_ptr)(wsrc[r] + t * BK),
+                                       (las_ptr)(base + BM * ROWB + (r * NW + wave) * 8 * ROWB), 16, 0, 0);
+  };
+  auto compute = [&](auto buf_c) {
+    constexpr int buf = decltype(buf_c)::value;
+    const char* Ab = smem + buf * TILEB;
+    const char* Wb = Ab + BM * ROWB;
+#pragma unroll
+    for (int ks = 0; ks < BK / 32; ++ks) {
+      short8 af[MI], bfr[NI];
+      const int c = ks * 4 + (lane >> 4);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int row = wr * TM + i * 16 + (lane & 15);
+        af[i] = *reinterpret_cast<const short8*>(Ab + row * ROWB + ((c ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int row = wc * TN + j * 16 + (lane & 15);
+        bfr[j] = *reinterpret_cast<const short8*>(Wb + row * ROWB + ((c ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);  // C^T tile
+    }
+  };
+  using B0 = std::integral_constant<int, 0>;
+  using B1 = std::integral_constant<int, 1>;
+  const int nt = a.K / BK;
+  stage(B0(), 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  for (int t = 0; t < nt; t += 2) {
+    if (t + 1 < nt) stage(B1(), t + 1);  // buffer 1 was last read for tile t-1: everyone passed the barrier since
+    compute(B0());
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // own DMA of tile t+1 landed ...
+    __builtin_amdgcn_s_barrier();                     // ... and so did everyone else's
+    if (t + 1 < nt) {
+      if (t + 2 < nt) stage(B0(), t + 2);
+      compute(B1());
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+  gemm_epilogue<T, MI, NI>(a, acc, m0 + wr * TM, n0 + wc * TN, z, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -266,11 +416,12 @@ void launch_gemm(const GemmArgs& a_in, hipStream_t s) {
   GemmArgs a = a_in;
   constexpr int VEC = Mma<T>::VEC;
   // ---- split-K decision: few 64x64 tiles, deep K, plain row-major output ----
-  if (sizeof(T) == 2 && a.batch == 1 && !a.row_map && a.M <= 512 && a.K >= 2048 && a.N % 4 == 0 && a.ldc % 4 == 0 &&
+  if (!getenv("ANYREF_GEMM_NO_SPLITK") && sizeof(T) == 2 && a.batch == 1 && !a.row_map && a.M <= 512 && a.K >= 2048 && a.N % 4 == 0 && a.ldc % 4 == 0 &&
       (!a.resid || a.ldr % 4 == 0)) {
-    const int64_t tiles = (int64_t)cdiv(a.M, 64) * cdiv(a.N, 64);
+    // 128 x 128 workgroups (two per CU): split until there are ~256 of them, slices of >= 512, multiples of 64
+    const int64_t tiles = (int64_t)cdiv(a.M, 128) * cdiv(a.N, 128);
     int splits = 1;
-    while (splits < 8 && tiles * splits < 1024 && (a.K / (splits * 2)) % 64 == 0 && a.K / (splits * 2) >= 512) splits *= 2;
+    while (splits < 8 && tiles * splits < 256 && (a.K / (splits * 2)) % 64 == 0 && a.K / (splits * 2) >= 512) splits *= 2;
     if (splits > 1) {
       const int64_t slab = (int64_t)a.M * a.N;
       float* ws = splitk_workspace(s, (size_t)splits * slab * sizeof(float));
@@ -328,6 +479,45 @@ void launch_gemm(const GemmArgs& a_in, hipStream_t s) {
   const double flops = 2.0 * a.M * a.N * (double)a.K * a.batch;
   const double bytes = ((double)a.M * a.K + (double)a.N * a.K) * sizeof(T) * a.batch +
                        (double)a.M * a.N * (a.c_f32 ? 4 : sizeof(T)) * a.batch;
+  if constexpr (sizeof(T) == 2) {
+    static const bool glds_off = getenv("ANYREF_GEMM_NO_GLDS") != nullptr;
+    if (!glds_off && a.K % 64 == 0 && !getenv("ANYREF_GEMM_TILE")) {
+      // Tile choice from scratch/lab/gemm_lab.hip on MI355X: 256^2 when its tiles fill whole rounds of the
+      // 256 CUs (SAM qkv: 240 tiles, square 8192^3), 64 x 256 for skinny-M / very wide N (prefill gate/up),
+      // otherwise 128^2 with 8 waves (two workgroups per CU).
+      auto go = [&](auto bm_t, auto bn_t, auto wm_t, auto wn_t, const char* tag) {
+        constexpr int BM = decltype(bm_t)::value, BN = decltype(bn_t)::value, WM = decltype(wm_t)::value,
+                      WN = decltype(wn_t)::value;
+        constexpr size_t lds = 2 * (size_t)(BM + BN) * 128;
+        auto kern = &gemm_glds_kernel<BM, BN, WM, WN>;
+        static bool attr = false;
+        if (!attr) {
+          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)lds));
+          attr = true;
+        }
+        if (getenv("ANYREF_GEMM_DEBUG")) fprintf(stderr, "[gemm] %s M=%d N=%d K=%d batch=%d\n", tag, a.M, a.N, a.K, a.batch);
+        ProfScope prof(tag, flops, bytes, s);
+        dim3 grid(cdiv(a.N, BN) * cdiv(a.M, BM), 1, a.batch);
+        hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, s, a);
+      };
+      using I1 = std::integral_constant<int, 1>;
+      using I2 = std::integral_constant<int, 2>;
+      using I4 = std::integral_constant<int, 4>;
+      using I64 = std::integral_constant<int, 64>;
+      using I128 = std::integral_constant<int, 128>;
+      using I256 = std::integral_constant<int, 256>;
+      const int64_t t256 = (int64_t)cdiv(a.M, 256) * cdiv(a.N, 256) * a.batch;
+      const double fill256 = (double)t256 / (double)(cdiv64(t256, 256) * 256);
+      if (a.M >= 1024 && fill256 >= 0.85)
+        go(I256(), I256(), I2(), I4(), "gemm_bf16_256x256");
+      else if (a.M <= 512 && a.N >= 16384)
+        go(I64(), I256(), I1(), I4(), "gemm_bf16_64x256");
+      else
+        go(I128(), I128(), I2(), I4(), "gemm_bf16_128x128g");
+      return;
+    }
+  }
   const char* tag = sizeof(T) == 2 ? (bm128 ? (bn == 128 ? "gemm_bf16_128x128" : "gemm_bf16_128x64")
                                             : (bn == 128 ? "gemm_bf16_64x128" : "gemm_bf16_64x64"))
                                    : (bm128 ? (bn == 128 ? "gemm_f32_128x128" : "gemm_f32_128x64")

@@ -3,10 +3,10 @@ sys.path.insert(0, '.')
 from anyref_amd import _lib
 lib = _lib.load()
 P = lambda t: C.c_void_p(t.data_ptr())
-shapes = [(320, 4096, 4096), (320, 4096, 11008), (257, 1024, 4096), (64, 128, 4096),
+shapes = [(4096, 3840, 1280), (4096, 1280, 1280), (4096, 5120, 1280), (4096, 1280, 5120), (4900, 3840, 1280), (4900, 1280, 1280),
           (320, 12288, 4096), (320, 4096, 4096), (320, 22016, 4096), (320, 4096, 11008),
-          (257, 3072, 1024), (257, 4096, 1024), (257, 1024, 4096), (8192, 8192, 8192)]
-print("mode", "old" if os.environ.get("ANYREF_GEMM_OLD") else "glds")
+          (257, 3072, 1024), (257, 1024, 1024), (257, 4096, 1024), (257, 1024, 4096), (8192, 8192, 8192)]
+print("mode", "register-staged" if os.environ.get("ANYREF_GEMM_NO_GLDS") else "glds", "splitk off" if os.environ.get("ANYREF_GEMM_NO_SPLITK") else "")
 for M, N, K in shapes:
     A = torch.randn(M, K, device='cuda').bfloat16(); W = (torch.randn(N, K, device='cuda') * 0.05).bfloat16()
     Cc = torch.empty(M, N, device='cuda', dtype=torch.bfloat16)
