@@ -65,6 +65,7 @@ SYMBOLS = {
     "anyref_profile_enable": (_I, [_P, _I]),
     "anyref_profile_config": (_I, [_P, C.c_char_p, _I]),
     "anyref_profile_collect": (_I, [_P]),
+    "anyref_profile_calibrate": (_I, [_P, _P, C.POINTER(C.c_double)]),
     "anyref_profile_read": (_I, [_P, _I, C.c_char_p, _I, C.POINTER(C.c_double), C.POINTER(_L),
                                 C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "anyref_device_bytes": (_L, [_P]),

@@ -137,6 +137,13 @@ int anyref_profile_config(anyref_handle* h, const char* only_tag, int sample_eve
 
 int anyref_profile_collect(anyref_handle* h) { GUARD(h, h->m->prof.collect()); }
 
+int anyref_profile_calibrate(anyref_handle* h, void* stream, double* overhead_us) {
+  GUARD(h, {
+    h->m->prof.calibrate((hipStream_t)stream);
+    if (overhead_us) *overhead_us = h->m->prof.null_ms * 1e3;
+  });
+}
+
 int anyref_profile_read(anyref_handle* h, int idx, char* name, int cap, double* ms, int64_t* count, double* flops,
                         double* bytes) {
   if (!h || !h->m) return -1;

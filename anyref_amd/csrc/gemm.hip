@@ -726,8 +726,10 @@ static void gemv_dispatch(const GemvArgs& a, int b0, int nb, hipStream_t s) {
     }
     // algorithmic bytes: every weight element once (+ the tiny activation / output vectors)
     const double wbytes = (double)a.N * a.K * sizeof(T) * (a.W2 ? 2 : 1) + (double)nb * (a.K + a.N) * 4;
-    ProfScope prof(sizeof(T) == 2 ? (a.W2 ? "gemv_bf16_swiglu" : "gemv_bf16") : (a.W2 ? "gemv_f32_swiglu" : "gemv_f32"),
-                   2.0 * nb * a.N * (double)a.K * (a.W2 ? 2 : 1), wbytes, s);
+    // one tag per kernel instantiation, so a tag's average can be checked against rocprofv3's per-kernel one
+    char tag[40];
+    snprintf(tag, sizeof(tag), "gemv_%s%s_x%d", sizeof(T) == 2 ? "bf16" : "f32", a.W2 ? "_swiglu" : "", XPT);
+    ProfScope prof(tag, 2.0 * nb * a.N * (double)a.K * (a.W2 ? 2 : 1), wbytes, s);
     if (a.W2)
       hipLaunchKernelGGL((gemv_kernel<T, NB, true, XPT>), dim3(grid), dim3(512), lds, s, a, b0, nb);
     else

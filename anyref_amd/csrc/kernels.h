@@ -28,8 +28,13 @@ class Profiler {
   void end(hipStream_t s);
   void collect();  // after the stream has been synchronised
   void reset();
+  // A bracket reads more than the kernel inside it (event packets are not free); that overhead is
+  // measured here with a tiny kernel (ops.hip; synchronises the stream) and taken off every bracket
+  // in collect(), so the booked time is the kernel's own duration.
+  void calibrate(hipStream_t s);
+  double null_ms = 0.0;
   bool on = false;
-  std::string filter;    // non-empty: only this tag is timed
+  std::string filter;    // non-empty: only tags starting with this are timed
   int sample_every = 1;  // time every n-th launch of a tag (keeps the event overhead out of the timed region)
   std::vector<std::pair<std::string, ProfStat>> stats() const;
 

@@ -1,5 +1,8 @@
 // Normalisation, data-movement and elementwise kernels (all HBM-bound; vectorised where the
 // layout allows, fp32 math throughout).
+#include <algorithm>
+#include <cstring>
+
 #include "kernels.h"
 
 namespace anyref {
@@ -13,7 +16,7 @@ Profiler::~Profiler() {
   }
 }
 bool Profiler::begin(const char* tag, double flops, double bytes, hipStream_t s) {
-  if (!filter.empty() && filter != tag) return false;
+  if (!filter.empty() && strncmp(tag, filter.c_str(), filter.size()) != 0) return false;  // prefix match
   int t = -1;
   for (size_t i = 0; i < tags_.size(); ++i)
     if (tags_[i] == tag) t = (int)i;
@@ -37,10 +40,52 @@ bool Profiler::begin(const char* tag, double flops, double bytes, hipStream_t s)
   return true;
 }
 void Profiler::end(hipStream_t s) { HIP_TRY(hipEventRecord(recs_.back().b, s)); }
+// calibration kernel: every wave spins on the 100 MHz wall clock for ~10 us (a duration of the order of
+// the kernels being timed; a near-empty kernel over-states the bracket cost of a real one by 2-3 us)
+__global__ void calib_spin_kernel(int ticks) {
+  const unsigned long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < (unsigned long long)ticks) __builtin_amdgcn_s_sleep(8);
+}
+void Profiler::calibrate(hipStream_t s) {
+  // What a bracket adds to the kernel inside it, in rocprofv3's accounting (back-to-back kernels of a
+  // stream abut): time [a K b] and [a K K b]; the second K costs E2 - E1, so the bracket costs 2 E1 - E2.
+  constexpr int N = 48;
+  std::vector<hipEvent_t> ev(4 * N);
+  for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
+  auto K = [&]() { hipLaunchKernelGGL(calib_spin_kernel, dim3(512), dim3(256), 0, s, 1000); };
+  for (int i = 0; i < N; ++i) {
+    HIP_TRY(hipEventRecord(ev[4 * i], s));
+    K();
+    HIP_TRY(hipEventRecord(ev[4 * i + 1], s));
+    HIP_TRY(hipEventRecord(ev[4 * i + 2], s));
+    K();
+    K();
+    HIP_TRY(hipEventRecord(ev[4 * i + 3], s));
+  }
+  HIP_TRY(hipStreamSynchronize(s));
+  std::vector<float> e1, e2;
+  for (int i = 0; i < N; ++i) {
+    float a = 0.f, b = 0.f;
+    if (hipEventElapsedTime(&a, ev[4 * i], ev[4 * i + 1]) == hipSuccess &&
+        hipEventElapsedTime(&b, ev[4 * i + 2], ev[4 * i + 3]) == hipSuccess) {
+      e1.push_back(a);
+      e2.push_back(b);
+    }
+  }
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  null_ms = 0.0;
+  if (!e1.empty()) {
+    std::sort(e1.begin(), e1.end());
+    std::sort(e2.begin(), e2.end());
+    const double m1 = e1[e1.size() / 2], m2 = e2[e2.size() / 2];
+    null_ms = std::max(0.0, 2.0 * m1 - m2);
+  }
+}
 void Profiler::collect() {
   for (auto& r : recs_) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
+    ms = ms > (float)null_ms ? ms - (float)null_ms : 0.f;
     ProfStat& st = stats_[r.tag];
     st.ms += ms;
     st.count += 1;

@@ -188,6 +188,10 @@ class AnyRefForCausalLM:
     def profile_enable(self, on: bool, only_tag: Optional[str] = None, sample_every: int = 1):
         self._check(self.lib.anyref_profile_config(self.h, only_tag.encode() if only_tag else None, sample_every),
                     "profile_config")
+        if on:  # what an empty event pair reads on this stream is taken off every bracket
+            ov = C.c_double()
+            self._check(self.lib.anyref_profile_calibrate(self.h, self._stream(), C.byref(ov)), "profile_calibrate")
+            self.profile_overhead_us = ov.value
         self._check(self.lib.anyref_profile_enable(self.h, int(on)), "profile_enable")
 
     def profile_read(self):

@@ -124,38 +124,45 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    # pre-pass: which kernel dominates the step?
+    # pre-pass: which kernel dominates the step?  Tags are per kernel INSTANTIATION (what rocprofv3 lists);
+    # the dominant kernel is the kernel template whose instantiations sum to the most device time.
+    def family(tag):
+        return "_".join(tag.split("_")[:2])              # gemv_bf16_swiglu_x8 -> gemv_bf16
+
     model.profile_enable(True)
     step()
     table = model.profile_read()
     model.profile_enable(False)
-    dom = max(table, key=lambda k: table[k]["ms"]) if table else None
+    fam_ms = {}
+    for k, v in table.items():
+        fam_ms[family(k)] = fam_ms.get(family(k), 0.0) + v["ms"]
+    dom = max(fam_ms, key=fam_ms.get) if fam_ms else None
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # hipEvent pairs around every 4th launch of the dominant kernel during the timed region (timing every
+    # hipEvent pairs around every 16th launch of the dominant kernel during the timed region (timing every
     # launch of every kernel costs ~4 us of dispatch gap each, 10 ms per step at 2300 launches)
-    model.profile_enable(True, only_tag=dom, sample_every=4)
+    model.profile_enable(True, only_tag=dom, sample_every=16)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         oids, masks = step()
     barrier()
     dt = time.perf_counter() - t0
-    timed = model.profile_read()
+    timed = {k: v for k, v in model.profile_read().items() if v["count"]}
     model.profile_enable(False)
     # the same kernel without a co-running stream (one extra, untimed step): the timed region overlaps the
     # SAM encoder with the decode loop, which inflates every co-running kernel's duration
-    iso = None
+    iso = {}
     if dom:
         model.set_overlap(False)
         step()
         model.profile_enable(True, only_tag=dom, sample_every=1)
         step()
-        iso = model.profile_read().get(dom)
+        iso = {k: v for k, v in model.profile_read().items() if v["count"]}
         model.profile_enable(False)
         model.set_overlap(True)
     tt = torch.tensor([dt], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
@@ -165,37 +172,49 @@ def main():
     ips = n_global * args.steps / dt
 
     roofline = None
-    if dom and dom in timed and timed[dom]["count"]:
-        st = timed[dom]
-        sec = st["ms"] / 1e3
+    if dom and timed:
         compute = dom.startswith(("gemm", "attn"))
-        if compute:
-            peak = PEAK_BF16_TFLOPS if "bf16" in dom else PEAK_F32_TFLOPS
-            ach = st["flops"] / sec / 1e12
-            roofline = dict(kernel=dom, bound="mfma", achieved=round(ach, 2), peak=peak, unit="TFLOP/s",
-                            frac=round(ach / peak, 4), traffic=None)
-        else:
-            ach = st["bytes"] / sec / 1e9
-            roofline = dict(kernel=dom, bound="hbm", achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit="GB/s",
-                            frac=round(ach / PEAK_HBM_GBS, 4), traffic=None)
-        if iso and iso["count"]:
-            k = (iso["flops"] / 1e12) if compute else (iso["bytes"] / 1e9)
-            roofline["isolated"] = {"achieved": round(k / (iso["ms"] / 1e3), 1), "frac": round(k / (iso["ms"] / 1e3) / roofline["peak"], 4),
-                                    "avg_launch_us": round(iso["ms"] * 1e3 / iso["count"], 2),
-                                    "note": "same kernel, SAM-encoder overlap off (no co-running stream)"}
-        per_step = table[dom]["count"]
-        roofline.update(launches_per_step=per_step, timed_launches=st["count"],
-                        avg_launch_us=round(st["ms"] * 1e3 / st["count"], 2),
-                        share_of_step=round(st["ms"] / st["count"] * per_step * args.steps / 1e3 / dt, 3))
-    # HBM traffic of that kernel from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same
-    # command (tools/pmc_summary.py -> profiles/pmc_traffic.json; counters cannot be read inside a timed run)
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        if roofline and args.config == "c2" and dom in pmc:
-            roofline["traffic"] = round(pmc[dom]["hbm_bytes_per_launch"])
-            roofline["algorithmic_bytes_per_launch"] = round(timed[dom]["bytes"] / timed[dom]["count"])
-    except (OSError, ValueError):
-        pass
+        peak = (PEAK_BF16_TFLOPS if "bf16" in dom else PEAK_F32_TFLOPS) if compute else PEAK_HBM_GBS
+        unit = "TFLOP/s" if compute else "GB/s"
+
+        def rate(v):  # algorithmic FLOPs (or bytes) of the timed launches / their summed duration
+            return (v["flops"] / 1e12 if compute else v["bytes"] / 1e9) / (v["ms"] / 1e3)
+
+        def total(d):
+            return {f: sum(v[f] for v in d.values()) for f in ("ms", "count", "flops", "bytes")}
+
+        tot = total(timed)
+        ach = rate(tot)
+        roofline = dict(kernel=dom, bound="mfma" if compute else "hbm", achieved=round(ach, 2 if compute else 1), peak=peak,
+                        unit=unit, frac=round(ach / peak, 4), traffic=None)
+        per_step = sum(v["count"] for k, v in table.items() if family(k) == dom)
+        roofline.update(event_pair_overhead_us=round(getattr(model, "profile_overhead_us", 0.0), 2),
+                        launches_per_step=per_step, timed_launches=tot["count"],
+                        avg_launch_us=round(tot["ms"] * 1e3 / tot["count"], 2),
+                        algorithmic_bytes_per_launch=round(tot["bytes"] / tot["count"]),
+                        share_of_step=round(tot["ms"] / tot["count"] * per_step * args.steps / 1e3 / dt, 3))
+        # per instantiation: what to hold against rocprofv3 --kernel-trace --stats (profiles/)
+        roofline["instantiations"] = {
+            k: dict(launches_per_step=table[k]["count"], avg_launch_us=round(v["ms"] * 1e3 / v["count"], 2),
+                    achieved=round(rate(v), 1), algorithmic_bytes_per_launch=round(v["bytes"] / v["count"]))
+            for k, v in sorted(timed.items())}
+        if iso:
+            ti = total(iso)
+            roofline["isolated"] = {"achieved": round(rate(ti), 1), "frac": round(rate(ti) / peak, 4),
+                                    "avg_launch_us": round(ti["ms"] * 1e3 / ti["count"], 2),
+                                    "instantiations": {k: dict(avg_launch_us=round(v["ms"] * 1e3 / v["count"], 2),
+                                                               achieved=round(rate(v), 1)) for k, v in sorted(iso.items())},
+                                    "note": "same kernels, SAM-encoder overlap off (no co-running stream)"}
+        # HBM traffic from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command
+        # (tools/pmc_summary.py -> profiles/pmc_traffic.json; counters cannot be read inside a timed run),
+        # averaged over the kernel's launches of one step
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            if args.config == "c2" and all(k in pmc for k in timed):
+                n = sum(table[k]["count"] for k in timed)
+                roofline["traffic"] = round(sum(pmc[k]["hbm_bytes_per_launch"] * table[k]["count"] for k in timed) / n)
+        except (OSError, ValueError, KeyError):
+            pass
     breakdown = {k: dict(ms_per_step=round(v["ms"], 3), launches=v["count"],
                          tflops=round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 1),
                          gbs=round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1)) for k, v in sorted(

@@ -179,6 +179,11 @@ int anyref_profile_enable(anyref_handle* h, int on);
  * event pairs do not perturb the timed region they measure. */
 int anyref_profile_config(anyref_handle* h, const char* only_tag, int sample_every);
 int anyref_profile_collect(anyref_handle* h);
+/* Measures what an event bracket adds to the kernel inside it on `stream` (tiny-kernel differencing;
+ * synchronises the stream) and takes it off every bracket booked afterwards, so a tag's time is the
+ * kernel's own duration (checked against rocprofv3 --kernel-trace in profiles/).  *overhead_us
+ * receives the value. */
+int anyref_profile_calibrate(anyref_handle* h, void* stream, double* overhead_us);
 int anyref_profile_read(anyref_handle* h, int idx, char* name, int cap, double* ms, int64_t* count,
                         double* flops, double* bytes);
 
