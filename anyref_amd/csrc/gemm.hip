@@ -9,6 +9,7 @@
 //
 // Structure: 256 threads = 4 waves as 2x2, block tile BM x BN x BK, register-prefetched global
 // loads (issue tile t+1 before computing tile t, write to LDS after the barrier: T14 split).
+#include <cmath>
 #include <cstdlib>
 #include <stdexcept>
 #include <utility>
@@ -270,8 +271,22 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs a) {
     const int q = nwg / 8, r = nwg % 8, xcd = id % 8;
     id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + id / 8;
   }
-  const int m0 = ((a.order & 2) ? id % tiles_m : id / tiles_n) * BM;
-  const int n0 = ((a.order & 2) ? id / tiles_m : id % tiles_n) * BN;
+  int tm, tn;
+  if (a.group_m > 0) {
+    // grouped order: GM tile rows at a time, column by column inside the group, so the contiguous chunk
+    // of tile ids one XCD receives is a GM x (chunk / GM) RECTANGLE of the output (its A rows stay in
+    // that XCD's L2, every W panel is fetched once per XCD) and the ~64 workgroups an XCD runs at once
+    // form a near-square block.  With plain M-fastest order an XCD walks whole columns and re-fetches
+    // all of A for each: 1.5-2x the L2-miss (fabric) traffic.
+    const int per = a.group_m * tiles_n, g = id / per, first = g * a.group_m;
+    const int gsz = tiles_m - first < a.group_m ? tiles_m - first : a.group_m;
+    tm = first + (id % per) % gsz;
+    tn = (id % per) / gsz;
+  } else {
+    tm = (a.order & 2) ? id % tiles_m : id / tiles_n;
+    tn = (a.order & 2) ? id / tiles_m : id % tiles_n;
+  }
+  const int m0 = tm * BM, n0 = tn * BN;
   const int z = blockIdx.z;
   const T* __restrict__ A = reinterpret_cast<const T*>(a.A) + (int64_t)z * a.sA;
   const T* __restrict__ W = reinterpret_cast<const T*>(a.W) + (int64_t)z * a.sW;
@@ -497,6 +512,13 @@ void launch_gemm(const GemmArgs& a_in, hipStream_t s) {
           attr = true;
         }
         if (getenv("ANYREF_GEMM_DEBUG")) fprintf(stderr, "[gemm] %s M=%d N=%d K=%d batch=%d\n", tag, a.M, a.N, a.K, a.batch);
+        {  // rows per group ~ sqrt(tiles one XCD gets), so its chunk is a near-square rectangle
+          const int tiles_m = cdiv(a.M, BM), nwg = tiles_m * cdiv(a.N, BN);
+          int gm = (int)lround(sqrt((double)(nwg > 8 ? nwg / 8 : 1)));
+          gm = gm < 1 ? 1 : (gm > tiles_m ? tiles_m : gm);
+          static const int gm_env = getenv("ANYREF_GEMM_GM") ? atoi(getenv("ANYREF_GEMM_GM")) : -1;
+          a.group_m = gm_env >= 0 ? gm_env : gm;
+        }
         ProfScope prof(tag, flops, bytes, s);
         dim3 grid(cdiv(a.N, BN) * cdiv(a.M, BM), 1, a.batch);
         hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, s, a);

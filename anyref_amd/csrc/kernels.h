@@ -77,6 +77,7 @@ struct GemmArgs {
   int c_f32 = 0;  // 1: C is f32, 0: C is T
   float alpha = 1.f;
   int order = 3;   // bit 0: XCD-chunked block remap, bit 1: M-fastest tile order
+  int group_m = 0;  // > 0 (set by the launcher): grouped tile order, this many tile rows per group
   int vec_ok = 0;  // set by the launcher: N / strides / bases allow 4-wide vector epilogue accesses
   // optional batching over blockIdx.z (element strides)
   int batch = 1;
