@@ -253,7 +253,16 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs a) {  // 2 waves/
 typedef const __attribute__((address_space(1))) void* gas_ptr;
 typedef __attribute__((address_space(3))) void* las_ptr;
 
-template <int BM, int BN, int WM, int WN>
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// NS stage buffers: tile t+NS-1 is requested right after the barrier of tile t and a counted vmcnt leaves
+// NS-2 tiles in flight across it.  NS = 2 (two workgroups per CU for the 128^2 tile) when there are more
+// tiles than CUs; NS = 3 when every workgroup has a CU to itself anyway (skinny-M prefill / CLIP shapes
+// whose W tiles come from HBM: prefill qkv 71 -> 51 us, CLIP fc1 18 -> 12 us with cold weights).
+template <int BM, int BN, int WM, int WN, int NS>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs a) {
   using T = bf16;
   constexpr int BK = 64, NW = WM * WN;
@@ -261,7 +270,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs a) {
   constexpr int ROWB = BK * 2;             // bytes per tile row
   constexpr int TILEB = (BM + BN) * ROWB;  // one stage
   constexpr int RA = BM / (NW * 8), RW = BN / (NW * 8);  // LDS-DMA rounds (8 rows per wave instruction)
+  constexpr int LPT = RA + RW;                           // DMA instructions per lane per tile
   static_assert(BM % (NW * 8) == 0 && BN % (NW * 8) == 0, "tile rows must split over the waves");
+  static_assert(NS >= 2 && NS <= 4 && (NS - 2) * LPT <= 63, "stage count / vmcnt range");
   extern __shared__ __attribute__((aligned(1024))) char smem[];  // the ONLY LDS object (rule: one array)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave / WN, wc = wave % WN;
@@ -355,23 +366,25 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs a) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);  // C^T tile
     }
   };
-  using B0 = std::integral_constant<int, 0>;
-  using B1 = std::integral_constant<int, 1>;
   const int nt = a.K / BK;
-  stage(B0(), 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  for (int t = 0; t < nt; t += 2) {
-    if (t + 1 < nt) stage(B1(), t + 1);  // buffer 1 was last read for tile t-1: everyone passed the barrier since
-    compute(B0());
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // own DMA of tile t+1 landed ...
-    __builtin_amdgcn_s_barrier();                     // ... and so did everyone else's
-    if (t + 1 < nt) {
-      if (t + 2 < nt) stage(B0(), t + 2);
-      compute(B1());
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-    }
+  static_for(std::make_integer_sequence<int, NS - 1>{}, [&](auto b) {  // prologue: tiles 0 .. NS-2
+    if (decltype(b)::value < nt) stage(b, decltype(b)::value);
+  });
+  for (int t0 = 0; t0 < nt; t0 += NS) {
+    static_for(std::make_integer_sequence<int, NS>{}, [&](auto b) {
+      constexpr int B = decltype(b)::value;
+      const int t = t0 + B;
+      if (t < nt) {
+        // own DMAs of tile t have landed once at most min(NS-2, nt-1-t) younger tiles are still in flight
+        const int behind = nt - 1 - t;
+        if (behind >= NS - 2) wait_vmcnt<(NS - 2) * LPT>();
+        else if (NS > 3 && behind == 1) wait_vmcnt<LPT>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();  // ... and so have everyone else's; all waves are done with tile t-1
+        if (t + NS - 1 < nt) stage(std::integral_constant<int, (B + NS - 1) % NS>(), t + NS - 1);  // into t-1's buffer
+        compute(b);
+      }
+    });
   }
   gemm_epilogue<T, MI, NI>(a, acc, m0 + wr * TM, n0 + wc * TN, z, lane);
 }
@@ -500,11 +513,11 @@ void launch_gemm(const GemmArgs& a_in, hipStream_t s) {
       // Tile choice from scratch/lab/gemm_lab.hip on MI355X: 256^2 when its tiles fill whole rounds of the
       // 256 CUs (SAM qkv: 240 tiles, square 8192^3), 64 x 256 for skinny-M / very wide N (prefill gate/up),
       // otherwise 128^2 with 8 waves (two workgroups per CU).
-      auto go = [&](auto bm_t, auto bn_t, auto wm_t, auto wn_t, const char* tag) {
+      auto go = [&](auto bm_t, auto bn_t, auto wm_t, auto wn_t, auto ns_t, const char* tag) {
         constexpr int BM = decltype(bm_t)::value, BN = decltype(bn_t)::value, WM = decltype(wm_t)::value,
-                      WN = decltype(wn_t)::value;
-        constexpr size_t lds = 2 * (size_t)(BM + BN) * 128;
-        auto kern = &gemm_glds_kernel<BM, BN, WM, WN>;
+                      WN = decltype(wn_t)::value, NS = decltype(ns_t)::value;
+        constexpr size_t lds = NS * (size_t)(BM + BN) * 128;
+        auto kern = &gemm_glds_kernel<BM, BN, WM, WN, NS>;
         static bool attr = false;
         if (!attr) {
           HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -525,18 +538,30 @@ void launch_gemm(const GemmArgs& a_in, hipStream_t s) {
       };
       using I1 = std::integral_constant<int, 1>;
       using I2 = std::integral_constant<int, 2>;
+      using I3 = std::integral_constant<int, 3>;
       using I4 = std::integral_constant<int, 4>;
       using I64 = std::integral_constant<int, 64>;
       using I128 = std::integral_constant<int, 128>;
       using I256 = std::integral_constant<int, 256>;
+      static int cus = 0;
+      if (!cus) {
+        int dev = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+      }
       const int64_t t256 = (int64_t)cdiv(a.M, 256) * cdiv(a.N, 256) * a.batch;
-      const double fill256 = (double)t256 / (double)(cdiv64(t256, 256) * 256);
+      const double fill256 = (double)t256 / (double)(cdiv64(t256, cus) * cus);
+      const int64_t t64w = (int64_t)cdiv(a.M, 64) * cdiv(a.N, 256) * a.batch;
+      const int64_t t128 = (int64_t)cdiv(a.M, 128) * cdiv(a.N, 128) * a.batch;
       if (a.M >= 1024 && fill256 >= 0.85)
-        go(I256(), I256(), I2(), I4(), "gemm_bf16_256x256");
-      else if (a.M <= 512 && a.N >= 16384)
-        go(I64(), I256(), I1(), I4(), "gemm_bf16_64x256");
+        go(I256(), I256(), I2(), I4(), I2(), "gemm_bf16_256x256");
+      else if (a.M <= 512 && a.N >= 8192) {
+        if (t64w <= cus) go(I64(), I256(), I1(), I4(), I3(), "gemm_bf16_64x256s3");
+        else go(I64(), I256(), I1(), I4(), I2(), "gemm_bf16_64x256");
+      } else if (t128 <= cus)
+        go(I128(), I128(), I2(), I4(), I3(), "gemm_bf16_128x128s3");
       else
-        go(I128(), I128(), I2(), I4(), "gemm_bf16_128x128g");
+        go(I128(), I128(), I2(), I4(), I2(), "gemm_bf16_128x128g");
       return;
     }
   }

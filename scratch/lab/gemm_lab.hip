@@ -10,6 +10,9 @@ using namespace anyref;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
 
 struct GA { const bf16* A; const bf16* W; bf16* C; int M, N, K; };
+#include <utility>
+template <int... Is, typename F>
+__device__ __forceinline__ void static_for(std::integer_sequence<int, Is...>, F&& f) { (f(std::integral_constant<int, Is>{}), ...); }
 
 // ---------------- V0: the shipped structure (single LDS buffer, write-before-barrier, 2 barriers per tile) --------------
 template <int BM, int BN>
@@ -255,6 +258,94 @@ __global__ __launch_bounds__(WM * WN * 64) void v2(GA a) {
     }
 }
 
+// ---------------- V3: V2 with NS stage buffers: tile t+NS-1 is requested right after the barrier of tile t,
+//                  counted vmcnt leaves NS-2 tiles in flight across the barrier ------------------------------------------
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int BM, int BN, int WM, int WN, int NS>
+__global__ __launch_bounds__(WM * WN * 64) void v3(GA a) {
+  constexpr int BK = 64, NT = WM * WN * 64, NW = WM * WN;
+  constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 16, NI = TN / 16;
+  constexpr int ROWB = BK * 2, TILEB = (BM + BN) * ROWB;
+  constexpr int RA = BM / (NW * 8), RW = BN / (NW * 8), LPT = RA + RW;
+  static_assert((NS - 2) * LPT <= 63, "vmcnt range");
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave / WN, wc = wave % WN;
+  const int tiles_m = cdiv(a.M, BM), tiles_n = cdiv(a.N, BN), nwg = tiles_m * tiles_n;
+  int id = blockIdx.x;
+  { const int q = nwg / 8, r = nwg % 8, xcd = id % 8; id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + id / 8; }
+  int gm = (int)(sqrtf((float)(nwg > 8 ? nwg / 8 : 1)) + 0.5f); gm = gm < 1 ? 1 : (gm > tiles_m ? tiles_m : gm);
+  const int per = gm * tiles_n, g = id / per, first = g * gm, gsz = tiles_m - first < gm ? tiles_m - first : gm;
+  const int m0 = (first + (id % per) % gsz) * BM, n0 = ((id % per) / gsz) * BN;
+  float4v acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = float4v{0, 0, 0, 0};
+  const int srow = lane >> 3, sp = lane & 7;
+  const bf16* asrc[RA]; const bf16* wsrc[RW];
+#pragma unroll
+  for (int r = 0; r < RA; ++r) { const int row = (r * NW + wave) * 8 + srow; int gmr = m0 + row; gmr = gmr < a.M ? gmr : a.M - 1; asrc[r] = a.A + (int64_t)gmr * a.K + ((sp ^ ((row >> 1) & 7)) << 3); }
+#pragma unroll
+  for (int r = 0; r < RW; ++r) { const int row = (r * NW + wave) * 8 + srow; int gn = n0 + row; gn = gn < a.N ? gn : a.N - 1; wsrc[r] = a.W + (int64_t)gn * a.K + ((sp ^ ((row >> 1) & 7)) << 3); }
+  auto stage = [&](auto buf_c, int t) {
+    constexpr int buf = decltype(buf_c)::value;
+    char* base = smem + buf * TILEB;
+#pragma unroll
+    for (int r = 0; r < RA; ++r) __builtin_amdgcn_global_load_lds((gas_ptr)(asrc[r] + t * BK), (las_ptr)(base + (r * NW + wave) * 8 * ROWB), 16, 0, 0);
+#pragma unroll
+    for (int r = 0; r < RW; ++r) __builtin_amdgcn_global_load_lds((gas_ptr)(wsrc[r] + t * BK), (las_ptr)(base + BM * ROWB + (r * NW + wave) * 8 * ROWB), 16, 0, 0);
+  };
+  auto compute = [&](auto buf_c) {
+    constexpr int buf = decltype(buf_c)::value;
+    const char* Ab = smem + buf * TILEB;
+    const char* Wb = Ab + BM * ROWB;
+#pragma unroll
+    for (int ks = 0; ks < BK / 32; ++ks) {
+      short8 af[MI], bfr[NI];
+      const int c = ks * 4 + (lane >> 4);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) { const int row = wr * TM + i * 16 + (lane & 15); af[i] = *reinterpret_cast<const short8*>(Ab + row * ROWB + ((c ^ ((row >> 1) & 7)) << 4)); }
+#pragma unroll
+      for (int j = 0; j < NI; ++j) { const int row = wc * TN + j * 16 + (lane & 15); bfr[j] = *reinterpret_cast<const short8*>(Wb + row * ROWB + ((c ^ ((row >> 1) & 7)) << 4)); }
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    }
+  };
+  const int nt = a.K / BK;
+  // prologue: tiles 0 .. NS-2 (nt >= NS-1 assumed by the host)
+  static_for(std::make_integer_sequence<int, NS - 1>{}, [&](auto b) { if (decltype(b)::value < nt) stage(b, decltype(b)::value); });
+  for (int t0 = 0; t0 < nt; t0 += NS) {
+    static_for(std::make_integer_sequence<int, NS>{}, [&](auto b) {
+      constexpr int B = decltype(b)::value;
+      const int t = t0 + B;
+      if (t < nt) {
+        // tiles still in flight behind tile t: min(NS-2, nt-1-t)
+        const int behind = nt - 1 - t;
+        if (behind >= NS - 2) wait_vm<(NS - 2) * LPT>();
+        else if (NS > 3 && behind == 1) wait_vm<LPT>();
+        else wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        if (t + NS - 1 < nt) stage(std::integral_constant<int, (B + NS - 1) % NS>(), t + NS - 1);
+        compute(b);
+      }
+    });
+  }
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int m = m0 + wr * TM + i * 16 + (lane & 15), n = n0 + wc * TN + j * 16 + 4 * (lane >> 4);
+      if (m < a.M && n < a.N) {
+        const float4v v = acc[i][j];
+        const uint32_t lo = (uint32_t)f2bf(v[0]).x | ((uint32_t)f2bf(v[1]).x << 16), hi = (uint32_t)f2bf(v[2]).x | ((uint32_t)f2bf(v[3]).x << 16);
+        *reinterpret_cast<uint2*>(a.C + (int64_t)m * a.N + n) = make_uint2(lo, hi);
+      }
+    }
+}
+
 template <typename K>
 static float run(K kern, int BM, int BN, size_t lds, GA a, int iters, int threads = 256) {
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -268,10 +359,21 @@ static float run(K kern, int BM, int BN, size_t lds, GA a, int iters, int thread
   return ms / iters * 1e3f;
 }
 
+template <typename K>
+static float run_cold(K kern, int BM, int BN, size_t lds, GA a, const std::vector<bf16*>& Ws, int iters, int threads) {
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  dim3 grid(cdiv(a.M, BM) * cdiv(a.N, BN));
+  for (size_t i = 0; i < Ws.size(); ++i) { a.W = Ws[i]; hipLaunchKernelGGL(kern, grid, dim3(threads), lds, 0, a); }
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  CK(hipEventRecord(e0, 0));
+  for (int i = 0; i < iters; ++i) { a.W = Ws[i % Ws.size()]; hipLaunchKernelGGL(kern, grid, dim3(threads), lds, 0, a); }
+  CK(hipEventRecord(e1, 0)); CK(hipDeviceSynchronize());
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+  return ms / iters * 1e3f;
+}
+
 int main() {
-  const int shapes[][3] = {{4096, 3840, 1280}, {4096, 1280, 1280}, {4096, 5120, 1280}, {4096, 1280, 5120}, {320, 12288, 4096},
-                           {320, 22016, 4096}, {320, 4096, 4096}, {320, 4096, 11008}, {577, 3072, 1024}, {577, 1024, 1024}, {577, 4096, 1024},
-                           {577, 1024, 4096}, {4900, 3840, 1280}, {4900, 1280, 1280}, {8192, 8192, 8192}};
+  const int shapes[][3] = {{320, 12288, 4096}, {320, 22016, 4096}, {4096, 3840, 1280}, {4096, 5120, 1280}, {4096, 1280, 5120}, {4900, 3840, 1280}, {257, 4096, 1024}};
   for (auto& sh : shapes) {
     const int M = sh[0], N = sh[1], K = sh[2];
     std::vector<uint16_t> hA((size_t)M * K), hW((size_t)N * K);
@@ -279,32 +381,36 @@ int main() {
     auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 65536.f * 2.f - 1.f; };
     for (auto& v : hA) v = f2bf_host(rnd()).x;
     for (auto& v : hW) v = f2bf_host(rnd() * 0.05f).x;
-    bf16 *A, *W, *C0, *C1;
-    CK(hipMalloc(&A, hA.size() * 2)); CK(hipMalloc(&W, hW.size() * 2)); CK(hipMalloc(&C0, (size_t)M * N * 2)); CK(hipMalloc(&C1, (size_t)M * N * 2));
-    CK(hipMemcpy(A, hA.data(), hA.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(W, hW.data(), hW.size() * 2, hipMemcpyHostToDevice));
+    bf16 *A, *C0, *C1;
+    CK(hipMalloc(&A, hA.size() * 2)); CK(hipMalloc(&C0, (size_t)M * N * 2)); CK(hipMalloc(&C1, (size_t)M * N * 2));
+    CK(hipMemcpy(A, hA.data(), hA.size() * 2, hipMemcpyHostToDevice));
+    const int nW = (int)(700e6 / ((double)N * K * 2)) + 1;   // rotate weights past the 256 MiB Infinity Cache
+    std::vector<bf16*> Ws(nW);
+    for (auto& w : Ws) { CK(hipMalloc(&w, hW.size() * 2)); CK(hipMemcpy(w, hW.data(), hW.size() * 2, hipMemcpyHostToDevice)); }
     const double fl = 2.0 * M * N * K;
-    const int it = M * (double)N * K > 1e11 ? 10 : 50;
-    GA a0{A, W, C0, M, N, K}, a1{A, W, C1, M, N, K};
-    const float t0 = run(v0<128, 128>, 128, 128, (128 + 128) * 72 * 2, a0, it);
-    const float t0b = run(v0<64, 128>, 64, 128, (64 + 128) * 72 * 2, a0, it);
-    const float t1 = run(v1<128, 128>, 128, 128, 2 * (128 + 128) * 72 * 2, a1, it);
-    // compare v1 128x128 against v0 128x128 (run last on C0?) -> rerun v0 128 into C0 for the check
-    run(v0<128, 128>, 128, 128, (128 + 128) * 72 * 2, a0, 1);
-    const float t1b = run(v1<64, 128>, 64, 128, 2 * (64 + 128) * 72 * 2, a1, it);
-    const float t2 = K % 64 ? 0.f : run(v2<256, 256, 2, 4>, 256, 256, 2 * 512 * 128, a1, it, 512);
-    const float t2b = K % 64 ? 0.f : run(v2<128, 256, 2, 4>, 128, 256, 2 * 384 * 128, a1, it, 512);
-    const float t2c = K % 64 ? 0.f : run(v2<256, 128, 4, 2>, 256, 128, 2 * 384 * 128, a1, it, 512);
-    const float t2d = K % 64 ? 0.f : run(v2<128, 128, 2, 4>, 128, 128, 2 * 256 * 128, a1, it, 512);
-    const float t2e = K % 64 ? 0.f : run(v2<128, 128, 2, 2>, 128, 128, 2 * 256 * 128, a1, it, 256);
-    const float t2f = K % 64 ? 0.f : run(v2<64, 256, 1, 4>, 64, 256, 2 * 320 * 128, a1, it, 256);
+    const int it = 40;
+    GA a0{A, Ws[0], C0, M, N, K}, a1{A, Ws[0], C1, M, N, K};
+    const float a_ = run_cold(v2<128, 128, 2, 4>, 128, 128, 2 * 256 * 128, a0, Ws, it, 512);
+    const float b_ = run_cold(v3<128, 128, 2, 4, 2>, 128, 128, 2 * 256 * 128, a1, Ws, it, 512);
+    const float c_ = run_cold(v3<128, 128, 2, 4, 3>, 128, 128, 3 * 256 * 128, a1, Ws, it, 512);
+    const float d_ = run_cold(v3<128, 128, 2, 4, 4>, 128, 128, 4 * 256 * 128, a1, Ws, it, 512);
+    const float e_ = run_cold(v2<64, 256, 1, 4>, 64, 256, 2 * 320 * 128, a1, Ws, it, 256);
+    const float f_ = run_cold(v3<64, 256, 1, 4, 3>, 64, 256, 3 * 320 * 128, a1, Ws, it, 256);
+    const float g_ = run_cold(v3<256, 256, 2, 4, 2>, 256, 256, 2 * 512 * 128, a1, Ws, it, 512);
+    // check: v3 NS=4 (last to write C1 among 128^2) vs v2: rerun both once
+    a0.W = Ws[0]; a1.W = Ws[0];
+    run_cold(v2<128, 128, 2, 4>, 128, 128, 2 * 256 * 128, a0, Ws, 1, 512);
+    run_cold(v3<128, 128, 2, 4, 4>, 128, 128, 4 * 256 * 128, a1, Ws, 1, 512);
     std::vector<uint16_t> h0((size_t)M * N), h1((size_t)M * N);
     CK(hipMemcpy(h0.data(), C0, h0.size() * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(h1.data(), C1, h1.size() * 2, hipMemcpyDeviceToHost));
     size_t bad = 0; for (size_t i = 0; i < h0.size(); ++i) bad += h0[i] != h1[i];
-    printf("      v2 256x256 %7.1f us %6.0f TF | v2 128x256 %7.1f us %6.0f TF | v2 256x128 %7.1f us | v2 128x128/8w %7.1f us | v2 128x128/4w %7.1f us | v2 64x256/4w %7.1f us\n", t2, fl / t2 / 1e6, t2b, fl / t2b / 1e6, t2c, t2d, t2e, t2f);
-    printf("M=%5d N=%6d K=%6d | v0 128x128 %7.1f us %6.0f TF | v0 64x128 %7.1f us %6.0f TF | v1 128x128 %7.1f us %6.0f TF | v1 64x128 %7.1f us %6.0f TF | mismatches %zu\n",
-           M, N, K, t0, fl / t0 / 1e6, t0b, fl / t0b / 1e6, t1, fl / t1 / 1e6, t1b, fl / t1b / 1e6, bad);
+    run_cold(v3<64, 256, 1, 4, 3>, 64, 256, 3 * 320 * 128, a1, Ws, 1, 256);
+    CK(hipMemcpy(h1.data(), C1, h1.size() * 2, hipMemcpyDeviceToHost));
+    size_t bad2 = 0; for (size_t i = 0; i < h0.size(); ++i) bad2 += h0[i] != h1[i];
+    printf("M=%5d N=%6d K=%5d cold(%d W) | 128^2: v2 %6.1f  v3/2 %6.1f  v3/3 %6.1f  v3/4 %6.1f | 64x256: v2 %6.1f  v3/3 %6.1f | 256^2 v3/2 %6.1f | mismatch %zu %zu\n",
+           M, N, K, nW, a_, b_, c_, d_, e_, f_, g_, bad, bad2);
     fflush(stdout);
-    hipFree(A); hipFree(W); hipFree(C0); hipFree(C1);
+    hipFree(A); hipFree(C0); hipFree(C1); for (auto w : Ws) hipFree(w);
   }
   return 0;
 }
