@@ -72,6 +72,8 @@ SYMBOLS = {
     "anyref_mode_name": (C.c_char_p, [_P]),
     # kernel-level test entry points (anyref_hip_ops.h)
     "anyref_op_gemm": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I]),
+    "anyref_op_iou_counts": (_I, [_P, _P, _P, _I, _L, _P]),
+    "anyref_op_sam_preprocess": (_I, [_P, _P, _I, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_float), _P]),
     "anyref_op_gemv": (_I, [_I, _P, _P, _P, _F, _P, _P, _P, _P, _P, _I, _I, _I, _I]),
     "anyref_op_norm": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _F, _I]),
     "anyref_op_attention": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P, _P, _P, _I, _I]),

@@ -849,4 +849,91 @@ void launch_to_f32(const void* in, int dtype, float* out, int64_t n, hipStream_t
   hipLaunchKernelGGL(to_f32_kernel, dim3(grid), dim3(256), 0, s, in, dtype, out, n);
 }
 
+// ---------------------------------------------------------------------------------------------
+// The steps either side of the path, integer / exact-f32 work, HBM-bound.
+// ---------------------------------------------------------------------------------------------
+// f-2: `(sigmoid(logit) > 0.5).int()` + intersectionAndUnionGPU(pred, gt, K=2, ignore_index=255)
+// (eval_referseg.py:189-208, utils/utils.py:79-91) fused: the full-resolution logits are read once
+// and never leave HBM.  counts[mask] = {I0, I1, O0, O1, T0, T1}: I_c = #{pred == gt == c},
+// O_c = #{pred == c, gt != 255}, T_c = #{gt == c}; union_c = O_c + T_c - I_c.  sigmoid(x) > 0.5 is
+// evaluated as x > 0 (identical except for 0 < x < ~1.2e-7, where the fp32 sigmoid rounds to 0.5).
+__global__ __launch_bounds__(256) void iou_counts_kernel(const float* __restrict__ logits,
+                                                         const uint8_t* __restrict__ target, int64_t hw,
+                                                         unsigned long long* __restrict__ counts) {
+  const int m = blockIdx.y;
+  const float* x = logits + (int64_t)m * hw;
+  const uint8_t* t = target + (int64_t)m * hw;
+  unsigned c[6] = {0, 0, 0, 0, 0, 0};
+  auto take = [&](float v, unsigned g) {
+    const unsigned p = v > 0.f ? 1u : 0u;
+    if (g != 255u) {
+      c[2 + p] += 1;
+      if (g < 2u) {
+        c[4 + g] += 1;
+        if (g == p) c[p] += 1;
+      }
+    }
+  };
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if ((hw & 3) == 0 && (((uintptr_t)x | (uintptr_t)t) & 15) == 0) {  // 4 pixels per step: 16 B of logits, 4 B of labels
+    for (int64_t i = i0; i < hw / 4; i += stride) {
+      const float4 v = reinterpret_cast<const float4*>(x)[i];
+      const uint32_t g = reinterpret_cast<const uint32_t*>(t)[i];
+      take(v.x, g & 255u); take(v.y, (g >> 8) & 255u); take(v.z, (g >> 16) & 255u); take(v.w, g >> 24);
+    }
+  } else {
+    for (int64_t i = i0; i < hw; i += stride) take(x[i], t[i]);
+  }
+  __shared__ unsigned red[4][6];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    unsigned v = c[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (lane == 0) red[wave][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {  // integer atomics: the result does not depend on the order of arrival
+    const unsigned v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    if (v) atomicAdd(&counts[(int64_t)m * 6 + threadIdx.x], (unsigned long long)v);
+  }
+}
+void launch_iou_counts(const float* logits, const uint8_t* target, int n, int64_t hw, int64_t* counts, hipStream_t s) {
+  if (n <= 0) return;
+  HIP_TRY(hipMemsetAsync(counts, 0, (size_t)n * 6 * sizeof(int64_t), s));
+  if (hw <= 0) return;
+  int64_t blocks = cdiv64(hw, 256 * 16);
+  blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
+  hipLaunchKernelGGL(iou_counts_kernel, dim3((unsigned)blocks, n), dim3(256), 0, s, logits, target, hw,
+                     reinterpret_cast<unsigned long long*>(counts));
+}
+
+// f-1: `sam_preprocess` (utils/refer_seg.py:560-570) on the resized uint8 HWC image: (x - mean) / std per
+// channel in f32 (IEEE division, bit-identical to the torch expression), CHW output zero-padded to S x S.
+__global__ __launch_bounds__(256) void sam_preprocess_kernel(const uint8_t* __restrict__ img, int h, int w, int S,
+                                                             float m0, float m1, float m2, float s0, float s1,
+                                                             float s2, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)S * S) return;
+  const int y = (int)(i / S), x = (int)(i % S);
+  float r = 0.f, g = 0.f, b = 0.f;  // F.pad pads the NORMALISED image with zeros
+  if (y < h && x < w) {
+    const uint8_t* p = img + ((int64_t)y * w + x) * 3;
+    r = ((float)p[0] - m0) / s0;
+    g = ((float)p[1] - m1) / s1;
+    b = ((float)p[2] - m2) / s2;
+  }
+  out[i] = r;
+  out[(int64_t)S * S + i] = g;
+  out[2 * (int64_t)S * S + i] = b;
+}
+void launch_sam_preprocess(const uint8_t* img, int h, int w, int S, const float* mean, const float* std_, float* out,
+                           hipStream_t s) {
+  if (h > S || w > S || h <= 0 || w <= 0) throw std::runtime_error("sam_preprocess: image larger than the SAM input");
+  hipLaunchKernelGGL(sam_preprocess_kernel, dim3((unsigned)cdiv64((int64_t)S * S, 256)), dim3(256), 0, s, img, h, w, S,
+                     mean[0], mean[1], mean[2], std_[0], std_[1], std_[2], out);
+}
+
 }  // namespace anyref

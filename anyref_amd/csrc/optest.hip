@@ -86,4 +86,14 @@ int anyref_op_postprocess(void* stream, const float* low, int n, int lh, int lw,
                           float* out) {
   OP_GUARD(launch_postprocess(low, (int64_t)lh * lw, n, lh, lw, S, rh, rw, H, W, out, (hipStream_t)stream));
 }
+
+int anyref_op_iou_counts(void* stream, const float* logits, const uint8_t* target, int n, int64_t hw,
+                         int64_t* counts) {
+  OP_GUARD(launch_iou_counts(logits, target, n, hw, counts, (hipStream_t)stream));
+}
+
+int anyref_op_sam_preprocess(void* stream, const uint8_t* img, int h, int w, int S, const float* mean3,
+                             const float* std3, float* out) {
+  OP_GUARD(launch_sam_preprocess(img, h, w, S, mean3, std3, out, (hipStream_t)stream));
+}
 }

@@ -28,6 +28,17 @@ int anyref_op_attention(int t, void* stream, const void* q, const void* k, const
 /* SAM decomposed rel-pos tables from q [B,S=size*size,H,hd] (type t) */
 int anyref_op_rel_pos(int t, void* stream, const void* q, const float* tab_h, const float* tab_w, int B, int H,
                       int size, int hd, float* rel_h, float* rel_w);
+/* SURVEY.md §8 f-2, replaces `(torch.sigmoid(pred) > 0.5).int()` + utils/utils.py:79-91
+ * intersectionAndUnionGPU(pred, gt, 2, ignore_index=255) (call site eval_referseg.py:189-208):
+ * logits f32 [n, hw] (device), target u8 [n, hw] with values 0 / 1 / 255 (device), counts i64 [n, 6]
+ * (device) = {I0, I1, O0, O1, T0, T1}; area_intersection = I, area_union = O + T - I, area_target = T. */
+int anyref_op_iou_counts(void* stream, const float* logits, const uint8_t* target, int n, int64_t hw,
+                         int64_t* counts);
+/* SURVEY.md §8 f-1, replaces `sam_preprocess` (utils/refer_seg.py:560-570) after ResizeLongestSide: img u8
+ * HWC [h, w, 3] (device) -> out f32 CHW [3, S, S] (device), (x - mean3[c]) / std3[c], zero padded; mean3 /
+ * std3 are HOST pointers. */
+int anyref_op_sam_preprocess(void* stream, const uint8_t* img, int h, int w, int S, const float* mean3,
+                             const float* std3, float* out);
 /* Sam.postprocess_masks on low [n,lh,lw] f32 */
 int anyref_op_postprocess(void* stream, const float* low, int n, int lh, int lw, int S, int rh, int rw, int H,
                           int W, float* out);

@@ -585,3 +585,34 @@ def anyref_forward(w: W, cfg, clip_images, sam_images, input_ids: List[torch.Ten
         dice = dice_loss_weight * dice / (nm + 1e-8)
         out.update(ce_loss=ce, dice_loss=dice, mask_loss=ce + dice, loss=lm_loss + ce + dice)
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# the steps right before / after the path (checkers for anyref_amd/evalops.py)
+# ---------------------------------------------------------------------------------------------
+def intersection_and_union(output: torch.Tensor, target: torch.Tensor, K: int, ignore_index: int = 255):
+    """utils/utils.py:79-91 intersectionAndUnionGPU, restated on CPU (integer label maps in, float counts out)."""
+    assert output.dim() in (1, 2, 3) and output.shape == target.shape
+    output = output.reshape(-1).clone().to(torch.int64)
+    target = target.reshape(-1).to(torch.int64)
+    output[target == ignore_index] = ignore_index
+    intersection = output[output == target]
+    area_intersection = torch.histc(intersection.float(), bins=K, min=0, max=K - 1)
+    area_output = torch.histc(output.float(), bins=K, min=0, max=K - 1)
+    area_target = torch.histc(target.float(), bins=K, min=0, max=K - 1)
+    return area_intersection, area_output + area_target - area_intersection, area_target
+
+
+def eval_mask_counts(pred_logits: torch.Tensor, gt_mask: torch.Tensor):
+    """eval_referseg.py:189-208: threshold the logits, then intersectionAndUnionGPU(pred, gt, 2, 255)."""
+    pred = (torch.sigmoid(pred_logits.float()) > 0.5).int()
+    return intersection_and_union(pred, gt_mask.int(), 2, ignore_index=255)
+
+
+def sam_preprocess(image_hwc_u8: torch.Tensor, sam_image_size: int = 1024,
+                   pixel_mean=(123.675, 116.28, 103.53), pixel_std=(58.395, 57.12, 57.375)):
+    """utils/refer_seg.py:560-570 on `torch.from_numpy(img).permute(2, 0, 1)` (`:588-590`)."""
+    x = image_hwc_u8.permute(2, 0, 1).contiguous().float()
+    x = (x - torch.tensor(pixel_mean).view(-1, 1, 1)) / torch.tensor(pixel_std).view(-1, 1, 1)
+    h, w = x.shape[-2:]
+    return F.pad(x, (0, sam_image_size - w, 0, sam_image_size - h))

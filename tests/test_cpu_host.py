@@ -119,3 +119,22 @@ def test_dp_gather_gloo_world2(tmp_path, n):
     for p in procs:
         out, _ = p.communicate(timeout=120)
         assert p.returncode == 0 and "OK" in out, out
+
+
+def test_oracle_eval_steps_known_answers():
+    """SURVEY.md §8 f-1 / f-2 restatements against hand-computed values (utils/utils.py:79-91,
+    utils/refer_seg.py:560-570)."""
+    import torch
+    from oracle import anyref_oracle as O
+    out = torch.tensor([[1, 1, 0, 0, 1, 0]])
+    tgt = torch.tensor([[1, 0, 0, 255, 255, 1]])
+    i, u, t = O.intersection_and_union(out, tgt, 2, ignore_index=255)
+    # ignored pixels leave every histogram; kept pixels: (1,1) (1,0) (0,0) (0,1)
+    assert i.tolist() == [1.0, 1.0] and t.tolist() == [2.0, 2.0] and u.tolist() == [3.0, 3.0]
+    logits = torch.tensor([[2.0, 0.5, -1.0, -3.0, 4.0, 0.0]])     # sigmoid(0) = 0.5 is not > 0.5
+    i2, u2, t2 = O.eval_mask_counts(logits, tgt)
+    assert (i2.tolist(), u2.tolist(), t2.tolist()) == (i.tolist(), u.tolist(), t.tolist())
+    img = torch.tensor([[[0, 128, 255]], [[255, 0, 128]]], dtype=torch.uint8)   # [2, 1, 3]
+    x = O.sam_preprocess(img, 4)
+    assert x.shape == (3, 4, 4) and float(x[:, 2:, :].abs().sum()) == 0 and float(x[:, :, 1:].abs().sum()) == 0
+    assert abs(float(x[0, 0, 0]) - (0 - 123.675) / 58.395) < 1e-6 and abs(float(x[2, 1, 0]) - (128 - 103.53) / 57.375) < 1e-6
