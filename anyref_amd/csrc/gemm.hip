@@ -637,46 +637,76 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int b0, int nb) {
   // x goes FIRST into the (in-order) vector-memory queue: its wait then leaves the weight prefetch
   // issued right behind it in flight.  Issued the other way round, the x wait also waited for the
   // first weight chunk (measured: x staged 4-9 us into a 10-22 us kernel).
-  float xr[NB][XPT], gr[XPT];
+  if (!a.gain) {
+    // no RMSNorm (o_proj / down_proj inputs): a plain f32 -> T copy with 16-byte loads.  The register
+    // path below issues XPT predicated dword loads per thread; at K = 11008 (XPT = 24) that staging
+    // alone cost ~3 us of a 21 us kernel.  Same values, same rounding: bit-identical.
+    constexpr int XV = (XPT + 3) / 4;  // float4 per thread
+    float4v xv[NB][XV];
 #pragma unroll
-  for (int i = 0; i < XPT; ++i) {  // RMSNorm gain rides in the same round trip as x
-    const int k = tid + i * 512;
-    gr[i] = (a.gain && k < K) ? a.gain[k] : 1.f;
-  }
+    for (int b = 0; b < NB; ++b) {
+      const float* x = a.x + (int64_t)(b0 + (b < nb ? b : 0)) * a.ldx;
 #pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    const float* x = a.x + (int64_t)(b0 + (b < nb ? b : 0)) * a.ldx;
-#pragma unroll
-    for (int i = 0; i < XPT; ++i) {
-      const int k = tid + i * 512;
-      xr[b][i] = (b < nb && k < K) ? x[k] : 0.f;
-    }
-  }
-  if (items > 0) load_item(0, wcur);
-#pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    if (b >= nb) continue;
-    float scale = 1.f;
-    if (a.gain) {
-      float ss = 0.f;
-#pragma unroll
-      for (int i = 0; i < XPT; ++i) ss += xr[b][i] * xr[b][i];
-      ss = wave_sum(ss);
-      if (lane == 0) red[b][wave] = ss;
-      __syncthreads();
-      float tot = 0.f;
-#pragma unroll
-      for (int w = 0; w < 8; ++w) tot += red[b][w];
-      scale = rsqrtf(tot / (float)K + a.eps);
-    }
-#pragma unroll
-    for (int i = 0; i < XPT; ++i) {
-      const int k = tid + i * 512;
-      if (k < K) {
-        xs[b * K + k] = from_f32<T>(xr[b][i] * scale * gr[i]);
+      for (int i = 0; i < XV; ++i) {
+        const int k = (tid + i * 512) * 4;
+        xv[b][i] = (b < nb && k < K) ? *reinterpret_cast<const float4v*>(x + k) : float4v{0.f, 0.f, 0.f, 0.f};
       }
     }
-  }
+    if (items > 0) load_item(0, wcur);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      if (b >= nb) continue;
+#pragma unroll
+      for (int i = 0; i < XV; ++i) {
+        const int k = (tid + i * 512) * 4;
+        if (k < K) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) xs[b * K + k + e] = from_f32<T>(xv[b][i][e]);
+        }
+      }
+    }
+  } else {
+    float xr[NB][XPT], gr[XPT];
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) {  // RMSNorm gain rides in the same round trip as x
+      const int k = tid + i * 512;
+      gr[i] = (a.gain && k < K) ? a.gain[k] : 1.f;
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const float* x = a.x + (int64_t)(b0 + (b < nb ? b : 0)) * a.ldx;
+#pragma unroll
+      for (int i = 0; i < XPT; ++i) {
+        const int k = tid + i * 512;
+        xr[b][i] = (b < nb && k < K) ? x[k] : 0.f;
+      }
+    }
+    if (items > 0) load_item(0, wcur);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      if (b >= nb) continue;
+      float scale = 1.f;
+      if (a.gain) {
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) ss += xr[b][i] * xr[b][i];
+        ss = wave_sum(ss);
+        if (lane == 0) red[b][wave] = ss;
+        __syncthreads();
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) tot += red[b][w];
+        scale = rsqrtf(tot / (float)K + a.eps);
+      }
+#pragma unroll
+      for (int i = 0; i < XPT; ++i) {
+        const int k = tid + i * 512;
+        if (k < K) {
+          xs[b * K + k] = from_f32<T>(xr[b][i] * scale * gr[i]);
+        }
+      }
+    }
+}
   __syncthreads();
 
   float acc[RW][NB];
@@ -796,6 +826,8 @@ template <typename T>
 void launch_gemv(const GemvArgs& a, hipStream_t s) {
   constexpr int VN = Vec16<T>::N;
   if (a.K % VN || ((uintptr_t)a.W & 15)) throw std::runtime_error("gemv: K must be a multiple of 16 bytes");
+  if (!a.gain && (((uintptr_t)a.x & 15) || a.ldx % 4 || a.K % 4))
+    throw std::runtime_error("gemv: x rows must be 16-byte aligned");
   constexpr int NBMAX = sizeof(T) == 2 ? 4 : 2;
   for (int b0 = 0; b0 < a.B; b0 += NBMAX) {
     const int nb = a.B - b0 < NBMAX ? a.B - b0 : NBMAX;

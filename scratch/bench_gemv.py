@@ -3,7 +3,7 @@ sys.path.insert(0, '.')
 from anyref_amd import _lib
 lib = _lib.load()
 P = lambda t: C.c_void_p(t.data_ptr())
-shapes = [(12288, 4096, 0, 1), (4096, 4096, 0, 0), (11008, 4096, 1, 1), (4096, 11008, 0, 0), (32007, 4096, 0, 1)]
+shapes = [(12288, 4096, 0, 1), (4096, 4096, 0, 0), (11008, 4096, 1, 1), (4096, 11008, 0, 0), (11008, 4096, 0, 0), (4096, 11008, 0, 1), (8192, 5504, 0, 0), (32007, 4096, 0, 1)]
 print("grid", os.environ.get("ANYREF_GEMV_GRID"))
 # rotate over several weight copies so the 256 MiB infinity cache cannot serve the stream
 for N, K, dual, norm in shapes:
