@@ -162,6 +162,9 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
 #pragma unroll
     for (int kk = 0; kk < HDK / KS; ++kk) qf[kk] = M_::glb(qrow, kk * KS, lane, q_ok, HD);
   }
+  // bf16 path: softmax in the log2 domain (one v_exp_f32 per score): scores and biases carry log2(e)
+  constexpr float LOG2E = 1.4426950408889634f;
+  const float bsc = BF ? LOG2E : 1.f;
   const bool has_rel = a.rel_h != nullptr || a.rel_p != nullptr;
   if (a.rel_p) {
     const float* P = a.rel_p + (int64_t)h * a.rel_hs + ((int64_t)b * a.Sq + q0) * a.rel_ld;
@@ -169,23 +172,23 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
     for (int i = tid; i < BQ * a.kh; i += 256) {
       const int r = i / a.kh, c = i % a.kh;
       const int y = (q0 + r) / a.kw;
-      relh_s[i] = q0 + r < q_len ? P[(int64_t)r * a.rel_ld + (y - c + a.kh - 1)] : 0.f;
+      relh_s[i] = q0 + r < q_len ? P[(int64_t)r * a.rel_ld + (y - c + a.kh - 1)] * bsc : 0.f;
     }
     for (int i = tid; i < BQ * a.kw; i += 256) {
       const int r = i / a.kw, c = i % a.kw;
       const int x = (q0 + r) % a.kw;
-      relw_s[i] = q0 + r < q_len ? P[(int64_t)r * a.rel_ld + np + (x - c + a.kw - 1)] : 0.f;
+      relw_s[i] = q0 + r < q_len ? P[(int64_t)r * a.rel_ld + np + (x - c + a.kw - 1)] * bsc : 0.f;
     }
   } else if (has_rel) {
     const float* rh = a.rel_h + ((int64_t)b * a.H + h) * a.Sq * a.kh;
     const float* rw = a.rel_w + ((int64_t)b * a.H + h) * a.Sq * a.kw;
     for (int i = tid; i < BQ * a.kh; i += 256) {
       const int r = i / a.kh, c = i % a.kh;
-      relh_s[i] = q0 + r < q_len ? rh[(int64_t)(q0 + r) * a.kh + c] : 0.f;
+      relh_s[i] = q0 + r < q_len ? rh[(int64_t)(q0 + r) * a.kh + c] * bsc : 0.f;
     }
     for (int i = tid; i < BQ * a.kw; i += 256) {
       const int r = i / a.kw, c = i % a.kw;
-      relw_s[i] = q0 + r < q_len ? rw[(int64_t)(q0 + r) * a.kw + c] : 0.f;
+      relw_s[i] = q0 + r < q_len ? rw[(int64_t)(q0 + r) * a.kw + c] * bsc : 0.f;
     }
   }
   // global-attention fast path: the key tile is exactly one bias row (kw == BKV, tiles aligned), so
@@ -207,25 +210,44 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
 #pragma unroll
   for (int d = 0; d < DB; ++d) ot[d] = float4v{0.f, 0.f, 0.f, 0.f};
 
+  // K [BKV][HDK] and V [BKV][HD] tiles, both row-major, 16-byte vectors.  Register-staged with the loads of
+  // tile t+1 issued BEFORE tile t is multiplied and written to LDS after the barrier that frees it (guide
+  // T14): staged synchronously, the waves spent 65 % of their cycles waiting on these loads (SQ_WAIT_ANY /
+  // SQ_WAVE_CYCLES on the SAM global-attention launch).
+  constexpr int KVEC = HDK / VEC, VVEC = HD / VEC;
+  constexpr int KPT = (BKV * KVEC + 255) / 256, VPT = (BKV * VVEC + 255) / 256;  // vectors per thread
+  uint4v kreg[KPT], vreg[VPT];
+  auto gload_tile = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+      const int v = tid + i * 256, row = v / KVEC, d = (v % KVEC) * VEC, j = kt + row;
+      kreg[i] = (v < BKV * KVEC && j < kv_end && d < HD) ? *reinterpret_cast<const uint4v*>(Kb + (int64_t)j * a.k_rs + d)
+                                                        : uint4v{0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+      const int v = tid + i * 256, row = v / VVEC, d = (v % VVEC) * VEC, j = kt + row;
+      vreg[i] = (v < BKV * VVEC && j < kv_end) ? *reinterpret_cast<const uint4v*>(Vb + (int64_t)j * a.v_rs + d)
+                                               : uint4v{0, 0, 0, 0};
+    }
+  };
+  auto sstore_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+      const int v = tid + i * 256, row = v / KVEC, d = (v % KVEC) * VEC;
+      if (v < BKV * KVEC) *reinterpret_cast<uint4v*>(&Ks[row * LDK + d]) = kreg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+      const int v = tid + i * 256, row = v / VVEC, d = (v % VVEC) * VEC;
+      if (v < BKV * VVEC) *reinterpret_cast<uint4v*>(&Vs[row * LDV + d]) = vreg[i];
+    }
+  };
+  if (kv_end > 0) gload_tile(0);
   for (int kt = 0; kt < kv_end; kt += BKV) {
-    // ---- stage K [BKV][HDK] and V [BKV][HD], both row-major, 16-byte vectors ------------------
-    constexpr int KVEC = HDK / VEC;
-    for (int v = tid; v < BKV * KVEC; v += 256) {
-      const int row = v / KVEC, d = (v % KVEC) * VEC;
-      const int j = kt + row;
-      uint4v val = uint4v{0, 0, 0, 0};
-      if (j < kv_end && d < HD) val = *reinterpret_cast<const uint4v*>(Kb + (int64_t)j * a.k_rs + d);
-      *reinterpret_cast<uint4v*>(&Ks[row * LDK + d]) = val;
-    }
-    constexpr int VVEC = HD / VEC;
-    for (int v = tid; v < BKV * VVEC; v += 256) {
-      const int row = v / VVEC, d = (v % VVEC) * VEC;
-      const int j = kt + row;
-      uint4v val = uint4v{0, 0, 0, 0};
-      if (j < kv_end) val = *reinterpret_cast<const uint4v*>(Vb + (int64_t)j * a.v_rs + d);
-      *reinterpret_cast<uint4v*>(&Vs[row * LDV + d]) = val;
-    }
+    sstore_tile();
     __syncthreads();
+    if (kt + BKV < kv_end) gload_tile(kt + BKV);
 
     // wave-uniform skips: rows past the end / tile entirely in the causal future of this row block
     const bool active = q0 + wave * 16 < q_len && !(a.causal && kt > pos0 + q0 + wave * 16 + 15);
@@ -251,42 +273,90 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
       float sv[NB][4];
       float mx = -INFINITY;
       const float relh_tile = rel_fast ? relh_s[il * a.kh + kt / BKV] : 0.f;
+      const float c1 = a.scale * bsc;
+      // masking only where a tile can hold an invalid key for one of this wave's 16 queries (wave-uniform)
+      const bool need_mask = kt + BKV > kv_len || (a.causal && kt + BKV - 1 > pos0 + q0 + wave * 16);
+      if (need_mask) {
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) {
+        for (int nb = 0; nb < NB; ++nb) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int j = kt + nb * 16 + 4 * g + r;
-          float s = st[nb][r] * a.scale;
-          if (rel_fast) {
-            s += relh_tile + relw_reg[nb][r];
-          } else if (has_rel) {
-            int jh = (int)(((unsigned)j * kw_magic) >> 20), jw = j - jh * a.kw;
-            if (jh >= a.kh) jh = 0, jw = 0;  // masked keys beyond kv_len: keep LDS reads in range
-            s += relh_s[il * a.kh + jh] + relw_s[il * a.kw + jw];
+          for (int r = 0; r < 4; ++r) {
+            const int j = kt + nb * 16 + 4 * g + r;
+            float s = st[nb][r] * c1;
+            if (rel_fast) {
+              s += relh_tile + relw_reg[nb][r];
+            } else if (has_rel) {
+              int jh = (int)(((unsigned)j * kw_magic) >> 20), jw = j - jh * a.kw;
+              if (jh >= a.kh) jh = 0, jw = 0;  // masked keys beyond kv_len: keep LDS reads in range
+              s += relh_s[il * a.kh + jh] + relw_s[il * a.kw + jw];
+            }
+            const bool valid = j < kv_len && (!a.causal || j <= pos0 + iq);
+            s = valid ? s : -INFINITY;
+            sv[nb][r] = s;
+            mx = fmaxf(mx, s);
           }
-          const bool valid = j < kv_len && (!a.causal || j <= pos0 + iq);
-          s = valid ? s : -INFINITY;
-          sv[nb][r] = s;
-          mx = fmaxf(mx, s);
+        }
+      } else {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float s;
+            if (rel_fast) {
+              s = fmaf(st[nb][r], c1, relh_tile + relw_reg[nb][r]);
+            } else if (has_rel) {
+              const int j = kt + nb * 16 + 4 * g + r;
+              const int jh = (int)(((unsigned)j * kw_magic) >> 20), jw = j - jh * a.kw;
+              s = fmaf(st[nb][r], c1, relh_s[il * a.kh + jh] + relw_s[il * a.kw + jw]);
+            } else {
+              s = st[nb][r] * c1;
+            }
+            sv[nb][r] = s;
+            mx = fmaxf(mx, s);
+          }
         }
       }
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run, mx);
-      const float mref = m_new == -INFINITY ? 0.f : m_new;
-      const float alpha = M_::fexp(m_run - mref);  // m_run = -inf -> 0
       float rs = 0.f;
+      if constexpr (BF) {
+        // lazy rescaling: keep the old reference maximum unless the new one exceeds it by 2^8 (then P <= 256,
+        // exactly representable scale in bf16 / f32), so O and l are rescaled in few tiles, and only when
+        // some lane of the wave moved its reference (wave-uniform branch)
+        const float m_new = mx > m_run + 8.f ? mx : m_run;  // m_run = -inf: any finite mx moves it
+        const bool moved = m_new != m_run;
+        const float mref = m_new == -INFINITY ? 0.f : m_new;
+        if (__builtin_amdgcn_ballot_w64(moved) != 0) {
+          const float alpha = __builtin_amdgcn_exp2f(m_run - mref);  // m_run = -inf -> 0; unmoved lanes: 2^0 = 1
+          l_run *= alpha;
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          sv[nb][r] = M_::fexp(sv[nb][r] - mref);  // masked: exp(-inf) = 0
-          rs += sv[nb][r];
+          for (int d = 0; d < DB; ++d) ot[d] *= alpha;
+          m_run = m_new;
         }
-      l_run = l_run * alpha + rs;
-      m_run = m_new;
 #pragma unroll
-      for (int d = 0; d < DB; ++d) ot[d] *= alpha;
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            sv[nb][r] = __builtin_amdgcn_exp2f(sv[nb][r] - mref);  // masked: 2^-inf = 0
+            rs += sv[nb][r];
+          }
+        l_run += rs;
+      } else {
+        const float m_new = fmaxf(m_run, mx);
+        const float mref = m_new == -INFINITY ? 0.f : m_new;
+        const float alpha = M_::fexp(m_run - mref);  // m_run = -inf -> 0
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            sv[nb][r] = M_::fexp(sv[nb][r] - mref);  // masked: exp(-inf) = 0
+            rs += sv[nb][r];
+          }
+        l_run = l_run * alpha + rs;
+        m_run = m_new;
+#pragma unroll
+        for (int d = 0; d < DB; ++d) ot[d] *= alpha;
+      }
       // ---- O^T += V^T P^T -----------------------------------------------------------------------
       if constexpr (BF) {
         // this lane's address inside its group's 4x16 block: row q = (lane&15)>>2, columns 4p

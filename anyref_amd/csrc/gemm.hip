@@ -60,9 +60,10 @@ __device__ __forceinline__ void static_for(std::integer_sequence<int, Is...>, F&
 // ACT and VEC are compile-time: the epilogue is fully unrolled over the wave's MI x NI fragments, and with
 // a runtime activation switch + both store paths inlined per fragment the 256 x 256 kernel was 45 k lines
 // of assembly whose (mostly skipped) epilogue cost ~20 us of a 65 us GEMM in instruction fetch.
-template <int ACT>
+template <int ACT, bool FAST>
 __device__ __forceinline__ float act_ct(float v) {
   if constexpr (ACT == ACT_NONE) return v;
+  else if constexpr (ACT == ACT_GELU && FAST) return gelu_fast(v);
   else return apply_act(v, ACT);
 }
 
@@ -71,7 +72,7 @@ __device__ __forceinline__ void epi_store4(const GemmArgs& a, const float* bias,
                                            int dm, int n, float4v v) {
   if constexpr (VEC) {  // N % 4 == 0: the four columns are all valid, rows are 16-byte aligned
     if (bias) v += *reinterpret_cast<const float4v*>(bias + n);
-    v = float4v{act_ct<ACT>(v[0]), act_ct<ACT>(v[1]), act_ct<ACT>(v[2]), act_ct<ACT>(v[3])};
+    v = float4v{act_ct<ACT, sizeof(T) == 2>(v[0]), act_ct<ACT, sizeof(T) == 2>(v[1]), act_ct<ACT, sizeof(T) == 2>(v[2]), act_ct<ACT, sizeof(T) == 2>(v[3])};
     if (resid) v += *reinterpret_cast<const float4v*>(resid + (int64_t)dm * a.ldr + n);
     if (a.c_f32) {
       *reinterpret_cast<float4v*>(Cf + (int64_t)dm * a.ldc + n) = v;
@@ -88,7 +89,7 @@ __device__ __forceinline__ void epi_store4(const GemmArgs& a, const float* bias,
       if (n + r < a.N) {
         float x = v[r];
         if (bias) x += bias[n + r];
-        x = act_ct<ACT>(x);
+        x = act_ct<ACT, sizeof(T) == 2>(x);
         if (resid) x += resid[(int64_t)dm * a.ldr + n + r];
         if (a.c_f32)
           Cf[(int64_t)dm * a.ldc + n + r] = x;
