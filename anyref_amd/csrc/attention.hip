@@ -125,7 +125,10 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
   constexpr int BQ = 64;
   constexpr int HDK = (HD + KS - 1) / KS * KS;  // QK^T contraction length (zero padded)
   constexpr int LDK = HDK + VEC;                // K tile row stride
-  constexpr int LDV = HD + VEC;                 // V tile row stride (row-major [key][d])
+  // V tile row stride (row-major [key][d]).  bf16: the transposed reads (ds_read_b64_tr_b16) fetch, per
+  // 16-lane group, 4 rows x 32 B; a stride of 32 B modulo the 256-B bank row lets 8 consecutive rows tile the
+  // banks (HD + 8 elements left them overlapping: 2x more conflict cycles than LDS-active cycles measured)
+  constexpr int LDV = BF ? ((HD * 2 + 255) / 256 * 256 + 32) / 2 : HD + VEC;
   constexpr int NB = BKV / 16;                  // key blocks of one tile
   constexpr int DB = HD / 16;                   // output d blocks
   static_assert(HD % 16 == 0, "head dim must be a multiple of 16");
@@ -415,7 +418,8 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
 template <typename T, int HD>
 static void attn_launch(const AttnArgs& a, hipStream_t s) {
   constexpr int KS = AMma<T>::KS, VEC = AMma<T>::VEC, BKV = AttnTile<T>::BKV;
-  constexpr int HDK = (HD + KS - 1) / KS * KS, LDK = HDK + VEC, LDV = HD + VEC;
+  constexpr int HDK = (HD + KS - 1) / KS * KS, LDK = HDK + VEC;
+  constexpr int LDV = sizeof(T) == 2 ? ((HD * 2 + 255) / 256 * 256 + 32) / 2 : HD + VEC;
   size_t lds = sizeof(T) * (BKV * LDK + BKV * LDV);
   if (a.rel_h || a.rel_p) lds += sizeof(float) * 64 * (a.kh + a.kw);
   if (lds > 160 * 1024) throw std::runtime_error("attention: LDS budget exceeded");
