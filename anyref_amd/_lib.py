@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(HERE, "libanyref_hip.so")
 
 ABI_VERSION = 1
 F32, BF16, F16 = 0, 1, 2
-MODE_PARITY, MODE_PERF = 0, 1
+MODE_PARITY, MODE_PERF, MODE_PERF_FP8W = 0, 1, 2
 
 
 class AnyrefConfig(C.Structure):
@@ -72,6 +72,8 @@ SYMBOLS = {
     "anyref_mode_name": (C.c_char_p, [_P]),
     # kernel-level test entry points (anyref_hip_ops.h)
     "anyref_op_gemm": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I]),
+    "anyref_op_quant_fp8": (_I, [_P, _P, _I, _I, _P, _P]),
+    "anyref_op_gemv_fp8": (_I, [_P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _I, _I, _I]),
     "anyref_op_iou_counts": (_I, [_P, _P, _P, _I, _L, _P]),
     "anyref_op_sam_preprocess": (_I, [_P, _P, _I, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_float), _P]),
     "anyref_op_gemv": (_I, [_I, _P, _P, _P, _F, _P, _P, _P, _P, _P, _I, _I, _I, _I]),

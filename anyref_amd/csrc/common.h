@@ -91,6 +91,20 @@ struct Vec16<float> {
   }
 };
 
+// ---- fp8 (OCP e4m3fn on gfx950) weight-only quantisation helpers ------------------------------
+typedef float float2v __attribute__((ext_vector_type(2)));
+// 16 bytes = 16 e4m3 values -> 16 floats (v_cvt_pk_f32_fp8: two per instruction, exact)
+__device__ inline void unpack_fp8x16(const uint4v& v, float* f) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int w = (int)v[i];
+    const float2v lo = __builtin_amdgcn_cvt_pk_f32_fp8(w, false);
+    const float2v hi = __builtin_amdgcn_cvt_pk_f32_fp8(w, true);
+    f[4 * i] = lo[0]; f[4 * i + 1] = lo[1]; f[4 * i + 2] = hi[0]; f[4 * i + 3] = hi[1];
+  }
+}
+constexpr float FP8_E4M3_MAX = 448.f;
+
 // ---- activations ---------------------------------------------------------------------------
 enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_QUICK_GELU = 3, ACT_SILU = 4 };
 

@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <stdexcept>
+#include <type_traits>
 #include <utility>
 #include <vector>
 #include "kernels.h"
@@ -594,9 +595,14 @@ template void launch_gemm<bf16>(const GemmArgs&, hipStream_t);
 // with 16-byte loads straight to VGPRs (no LDS round trip for once-read weights:
 // cdna_hip_programming.md §5 "GEMV / M <= 16" row) and reduces across the wave.
 // ---------------------------------------------------------------------------------------------
-template <typename T, int NB, bool DUAL, int XPT>  // XPT: x elements per thread held in registers, K <= 512 * XPT
+// W8: weights are fp8 e4m3 bytes with one f32 scale per output row (weight-only quantisation, activations
+// stay T = bf16): 16 weights per 16-byte load, converted two at a time by v_cvt_pk_f32_fp8, the row scale
+// applied once to the reduced sum.  Half the HBM bytes per step of the bf16 stream.
+template <typename T, int NB, bool DUAL, int XPT, bool W8 = false>  // XPT: x elements per thread in registers, K <= 512 * XPT
 __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int b0, int nb) {
-  constexpr int VN = Vec16<T>::N;
+  static_assert(!W8 || sizeof(T) == 2, "fp8 weights go with bf16 activations");
+  using WT = std::conditional_t<W8, uint8_t, T>;
+  constexpr int VN = W8 ? 16 : Vec16<T>::N;  // weights per 16-byte load
   constexpr int R = DUAL ? 1 : 2;   // output rows per wave per pass
   constexpr int RW = 2;             // weight rows streamed per pass (DUAL: gate row + up row)
   constexpr int UNR = 4;            // 16-byte loads per row in flight per lane (8 measured slower)
@@ -606,8 +612,8 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int b0, int nb) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int K = a.K;
 
-  const T* __restrict__ W = reinterpret_cast<const T*>(a.W);
-  const T* __restrict__ W2 = reinterpret_cast<const T*>(a.W2);
+  const WT* __restrict__ W = reinterpret_cast<const WT*>(a.W);
+  const WT* __restrict__ W2 = reinterpret_cast<const WT*>(a.W2);
   const int nwaves = gridDim.x * 8;
   const int gw = blockIdx.x * 8 + wave;
   const int ngroups = cdiv(a.N, R);
@@ -726,8 +732,12 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int b0, int nb) {
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
           if (b < nb) {
-            const uint4v xv = *reinterpret_cast<const uint4v*>(&xs[b * K + k]);
-            Vec16<T>::unpack(xv, xf[b]);
+            constexpr int XV = Vec16<T>::N;  // x elements per 16-byte LDS read
+#pragma unroll
+            for (int h = 0; h < VN / XV; ++h) {
+              const uint4v xv = *reinterpret_cast<const uint4v*>(&xs[b * K + k + h * XV]);
+              Vec16<T>::unpack(xv, &xf[b][h * XV]);
+            }
           } else {
 #pragma unroll
             for (int i = 0; i < VN; ++i) xf[b][i] = 0.f;
@@ -736,7 +746,8 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int b0, int nb) {
 #pragma unroll
         for (int r = 0; r < RW; ++r) {
           float wf[VN];
-          Vec16<T>::unpack(wcur[u][r], wf);
+          if constexpr (W8) unpack_fp8x16(wcur[u][r], wf);
+          else Vec16<T>::unpack(wcur[u][r], wf);
 #pragma unroll
           for (int b = 0; b < NB; ++b)
 #pragma unroll
@@ -759,9 +770,14 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int b0, int nb) {
           for (int b = 0; b < NB; ++b) {
             if (b >= nb) continue;
             float v = acc[r][b];
+            float v2 = DUAL ? acc[RW - 1][b] : 0.f;
+            if constexpr (W8) {
+              v *= a.wscale[n];
+              if (DUAL) v2 *= a.wscale2[n];
+            }
             if (a.bias) v += a.bias[n];
             if (DUAL)
-              v = apply_act(v, ACT_SILU) * acc[RW - 1][b];
+              v = apply_act(v, ACT_SILU) * v2;
             else
               v = apply_act(v, a.act);
             const int64_t o = (int64_t)(b0 + b) * a.ldy + n;
@@ -803,11 +819,30 @@ static void gemv_dispatch(const GemvArgs& a, int b0, int nb, hipStream_t s) {
       attr_set = true;
     }
     // algorithmic bytes: every weight element once (+ the tiny activation / output vectors)
-    const double wbytes = (double)a.N * a.K * sizeof(T) * (a.W2 ? 2 : 1) + (double)nb * (a.K + a.N) * 4;
+    const double wsz = a.w_fp8 ? 1.0 : (double)sizeof(T);
+    const double wbytes = (double)a.N * a.K * wsz * (a.W2 ? 2 : 1) + (double)nb * (a.K + a.N) * 4;
     // one tag per kernel instantiation, so a tag's average can be checked against rocprofv3's per-kernel one
     char tag[40];
-    snprintf(tag, sizeof(tag), "gemv_%s%s_x%d", sizeof(T) == 2 ? "bf16" : "f32", a.W2 ? "_swiglu" : "", XPT);
+    snprintf(tag, sizeof(tag), "gemv_%s%s_x%d", a.w_fp8 ? "fp8w" : (sizeof(T) == 2 ? "bf16" : "f32"),
+             a.W2 ? "_swiglu" : "", XPT);
     ProfScope prof(tag, 2.0 * nb * a.N * (double)a.K * (a.W2 ? 2 : 1), wbytes, s);
+    if constexpr (sizeof(T) == 2) {
+      if (a.w_fp8) {
+        static bool attr8 = false;
+        if (!attr8) {
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_kernel<T, NB, true, XPT, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_kernel<T, NB, false, XPT, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+          attr8 = true;
+        }
+        if (a.W2)
+          hipLaunchKernelGGL((gemv_kernel<T, NB, true, XPT, true>), dim3(grid), dim3(512), lds, s, a, b0, nb);
+        else
+          hipLaunchKernelGGL((gemv_kernel<T, NB, false, XPT, true>), dim3(grid), dim3(512), lds, s, a, b0, nb);
+        return;
+      }
+    }
     if (a.W2)
       hipLaunchKernelGGL((gemv_kernel<T, NB, true, XPT>), dim3(grid), dim3(512), lds, s, a, b0, nb);
     else
@@ -825,8 +860,10 @@ static void gemv_dispatch(const GemvArgs& a, int b0, int nb, hipStream_t s) {
 
 template <typename T>
 void launch_gemv(const GemvArgs& a, hipStream_t s) {
-  constexpr int VN = Vec16<T>::N;
+  const int VN = a.w_fp8 ? 16 : Vec16<T>::N;
   if (a.K % VN || ((uintptr_t)a.W & 15)) throw std::runtime_error("gemv: K must be a multiple of 16 bytes");
+  if (a.w_fp8 && (sizeof(T) != 2 || !a.wscale || (a.W2 && !a.wscale2)))
+    throw std::runtime_error("gemv: fp8 weights need the bf16 mode and per-row scales");
   if (!a.gain && (((uintptr_t)a.x & 15) || a.ldx % 4 || a.K % 4))
     throw std::runtime_error("gemv: x rows must be 16-byte aligned");
   constexpr int NBMAX = sizeof(T) == 2 ? 4 : 2;

@@ -99,9 +99,19 @@ struct GemvArgs {
   const float* resid = nullptr;  // f32 [B,N] row stride ldy, may alias y
   int B = 1, N = 0, K = 0, ldx = 0, ldy = 0;
   int act = ACT_NONE;
+  // fp8 weight-only mode (T = bf16 activations): W / W2 are e4m3 bytes [N,K], y = (sum_k x q) * wscale[n]
+  int w_fp8 = 0;
+  const float* wscale = nullptr;
+  const float* wscale2 = nullptr;
 };
 template <typename T>
 void launch_gemv(const GemvArgs& a, hipStream_t s);
+// Row-wise fp8 (e4m3fn) weight quantisation: scale[n] = max|W[n,:]| / 448 (1 if the row is zero),
+// q[n,k] = RNE_e4m3(W[n,k] / scale[n]); src f32 [N, K] (row stride lds), q [N, K] bytes (row stride ldq)
+void launch_quant_fp8_rows(const float* src, int lds, int N, int K, uint8_t* q, int ldq, float* scale, hipStream_t s);
+// q * scale -> bf16 [N, K] (prefill GEMM operand)
+void launch_dequant_fp8_rows(const uint8_t* q, int ldq, const float* scale, int N, int K, void* out_bf16, int ldo,
+                             hipStream_t s);
 
 // y[dst(m)] = LN(x[m]) * g + b   (rms: y = x * rsqrt(mean x^2 + eps) * g)
 struct NormArgs {

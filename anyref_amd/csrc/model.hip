@@ -98,6 +98,9 @@ struct Lin {  // nn.Linear packed in T
   T* w = nullptr;
   float* b = nullptr;
   int n = 0, k = 0;  // k = padded row length
+  // fp8 weight-only mode (LLM linears): e4m3 bytes [n, k] + one f32 scale per output row; w stays null
+  uint8_t* w8 = nullptr;
+  float* ws = nullptr;
 };
 struct LinF {  // nn.Linear kept in f32
   float* w = nullptr;
@@ -112,14 +115,17 @@ struct Affine {
 template <typename T>
 class Model : public ModelBase {
  public:
-  Model(const anyref_config& c, int device) : ModelBase(c, device) {}
+  Model(const anyref_config& c, int device) : ModelBase(c, device) {
+    fp8w_ = c.mode == ANYREF_MODE_PERF_FP8W;
+    if (fp8w_ && sizeof(T) != 2) throw std::runtime_error("fp8 weights need the bf16 compute mode");
+  }
   ~Model() override {
     (void)hipSetDevice(device_);
     (void)hipDeviceSynchronize();
     for (auto& kv : decode_graphs_) (void)hipGraphExecDestroy(kv.second);
     if (cap_stream_) (void)hipStreamDestroy(cap_stream_);
   }
-  const char* mode_name() const override { return sizeof(T) == 2 ? "bf16" : "f32"; }
+  const char* mode_name() const override { return sizeof(T) == 2 ? (fp8w_ ? "bf16+fp8w" : "bf16") : "f32"; }
   void finalize() override;
   void generate(hipStream_t s, const float* clip_images, const float* sam_images, const int64_t* input_ids,
                 const int32_t* lens, int B, int Lmax, const float* extra_embeds, const int32_t* extra_slots,
@@ -159,7 +165,47 @@ class Model : public ModelBase {
     GemmArgs a;
     a.A = A; a.lda = lda; a.W = l.w; a.ldw = l.k; a.bias = l.b; a.C = C; a.ldc = ldc; a.M = M; a.N = l.n;
     a.K = l.k; a.act = act; a.c_f32 = c_f32 ? 1 : 0; a.resid = resid; a.ldr = ldr; a.row_map = row_map;
+    if (l.w8) {  // fp8 weights: the M > 16 GEMM multiplies a bf16 image of q * scale (decode streams the bytes)
+      launch_dequant_fp8_rows(l.w8, l.k, l.ws, l.n, l.k, deq_buf_, l.k, s);
+      a.W = deq_buf_;
+    }
     launch_gemm<T>(a, s);
+  }
+  // nn.Linear (or a row range of a fused one) as the weight operand of a decode GEMV
+  void gemv_w(GemvArgs& g, const Lin<T>& l, int row0 = 0) const {
+    if (l.w8) {
+      g.W = l.w8 + (size_t)row0 * l.k;
+      g.wscale = l.ws + row0;
+      g.w_fp8 = 1;
+    } else {
+      g.W = l.w + (size_t)row0 * l.k;
+    }
+  }
+  void gemv_w2(GemvArgs& g, const Lin<T>& l, int row0) const {
+    if (l.w8) {
+      g.W2 = l.w8 + (size_t)row0 * l.k;
+      g.wscale2 = l.ws + row0;
+    } else {
+      g.W2 = l.w + (size_t)row0 * l.k;
+    }
+  }
+  bool fp8w_ = false;
+  T* deq_buf_ = nullptr;  // bf16 image of the largest fp8 weight (prefill operand)
+  // pack rows of a raw f32 tensor as fp8 + scales into l (rows [row0, row0 + rows))
+  void pack_rows_fp8(Lin<T>& l, int row0, const std::string& name, int rows, int cols) {
+    const RawTensor& t = raw(name);
+    if (t.numel() != (int64_t)rows * cols || cols != l.k)
+      throw std::runtime_error("shape mismatch for " + name + " (fp8 pack)");
+    launch_quant_fp8_rows(t.p, cols, rows, cols, l.w8 + (size_t)row0 * l.k, l.k, l.ws + row0, 0);
+  }
+  Lin<T> alloc_fp8(int n, int k) {
+    if (k % 16) throw std::runtime_error("fp8 weights need K % 16 == 0");
+    Lin<T> l;
+    l.n = n;
+    l.k = k;
+    l.w8 = reinterpret_cast<uint8_t*>(dalloc((size_t)n * k));
+    l.ws = talloc<float>(n);
+    return l;
   }
   void gemmf(hipStream_t s, const float* A, int lda, const LinF& l, float* C, int ldc, int M, int act,
              const float* resid = nullptr, int ldr = 0) {
@@ -419,21 +465,33 @@ void Model<T>::finalize() {
       LlmLayer& L = llm_layers_[i];
       L.in_norm = affine(lp + "input_layernorm", false);
       L.post_norm = affine(lp + "post_attention_layernorm", false);
-      L.qkv.n = 3 * H;
-      L.qkv.k = H;
-      L.qkv.w = talloc<T>((size_t)3 * H * H);
       const char* names[3] = {"q_proj", "k_proj", "v_proj"};
-      for (int j = 0; j < 3; ++j) pack_rows(L.qkv.w, j * H, lp + "self_attn." + names[j] + ".weight", H, H, H);
-      L.o = pack_linear(lp + "self_attn.o_proj.weight", "", H, H);
-      L.gu.n = 2 * F;
-      L.gu.k = H;
-      L.gu.w = talloc<T>((size_t)2 * F * H);
-      pack_rows(L.gu.w, 0, lp + "mlp.gate_proj.weight", F, H, H);
-      pack_rows(L.gu.w, F, lp + "mlp.up_proj.weight", F, H, H);
-      L.gate_w = L.gu.w;
-      L.up_w = L.gu.w + (size_t)F * H;
-      L.down = pack_linear(lp + "mlp.down_proj.weight", "", H, F);
-      if (L.down.k != F) throw std::runtime_error("llm_mlp must be a multiple of 8");
+      if (fp8w_) {
+        L.qkv = alloc_fp8(3 * H, H);
+        for (int j = 0; j < 3; ++j) pack_rows_fp8(L.qkv, j * H, lp + "self_attn." + names[j] + ".weight", H, H);
+        L.o = alloc_fp8(H, H);
+        pack_rows_fp8(L.o, 0, lp + "self_attn.o_proj.weight", H, H);
+        L.gu = alloc_fp8(2 * F, H);
+        pack_rows_fp8(L.gu, 0, lp + "mlp.gate_proj.weight", F, H);
+        pack_rows_fp8(L.gu, F, lp + "mlp.up_proj.weight", F, H);
+        L.down = alloc_fp8(H, F);
+        pack_rows_fp8(L.down, 0, lp + "mlp.down_proj.weight", H, F);
+      } else {
+        L.qkv.n = 3 * H;
+        L.qkv.k = H;
+        L.qkv.w = talloc<T>((size_t)3 * H * H);
+        for (int j = 0; j < 3; ++j) pack_rows(L.qkv.w, j * H, lp + "self_attn." + names[j] + ".weight", H, H, H);
+        L.o = pack_linear(lp + "self_attn.o_proj.weight", "", H, H);
+        L.gu.n = 2 * F;
+        L.gu.k = H;
+        L.gu.w = talloc<T>((size_t)2 * F * H);
+        pack_rows(L.gu.w, 0, lp + "mlp.gate_proj.weight", F, H, H);
+        pack_rows(L.gu.w, F, lp + "mlp.up_proj.weight", F, H, H);
+        L.gate_w = L.gu.w;
+        L.up_w = L.gu.w + (size_t)F * H;
+        L.down = pack_linear(lp + "mlp.down_proj.weight", "", H, F);
+        if (L.down.k != F) throw std::runtime_error("llm_mlp must be a multiple of 8");
+      }
       // free the raw copies of this layer early (7B in f32 is 27 GB)
       HIP_TRY(hipStreamSynchronize(0));
       for (const char* nm : {"self_attn.q_proj.weight", "self_attn.k_proj.weight", "self_attn.v_proj.weight",
@@ -447,7 +505,14 @@ void Model<T>::finalize() {
       }
     }
     llm_norm_ = affine("model.norm", false);
-    lm_head_ = pack_linear("lm_head.weight", "", V, H);
+    if (fp8w_) {
+      lm_head_ = alloc_fp8(V, H);
+      pack_rows_fp8(lm_head_, 0, "lm_head.weight", V, H);
+      const size_t big = std::max((size_t)2 * F * H, std::max((size_t)3 * H * H, (size_t)V * H));
+      deq_buf_ = talloc<T>(big);
+    } else {
+      lm_head_ = pack_linear("lm_head.weight", "", V, H);
+    }
     // rotary table, same fp32 op order as HF LlamaRotaryEmbedding
     std::vector<float> tab((size_t)S * hd);
     for (int pos = 0; pos < S; ++pos)
@@ -871,7 +936,7 @@ void Model<T>::llm_decode_step(hipStream_t s, int B, bool keep_q) {
   launch_embed_rows(next_dev_, B, emb_table_, sizeof(T) == 2, H, d_x_, s);
   launch_decode_index(pos_dev_, B, S, rowmap_dev_, kvlen_dev_, s);
   bool layers_done = false;
-  if (persistent_decode_) {
+  if (persistent_decode_ && !fp8w_) {
     DecodeStepArgs da;
     da.layers = llm_dec_ptrs_; da.nl = nl; da.B = B; da.H = H; da.F = F; da.nh = nh; da.maxS = S;
     da.eps = c.llm_rms_eps; da.scale = 1.f / sqrtf((float)hd);
@@ -884,7 +949,7 @@ void Model<T>::llm_decode_step(hipStream_t s, int B, bool keep_q) {
     T* kc = kcache_ + cache_layer_stride_ * i;
     T* vc = vcache_ + cache_layer_stride_ * i;
     GemvArgs g;
-    g.x = d_x_; g.ldx = H; g.gain = L.in_norm.g; g.eps = c.llm_rms_eps; g.W = L.qkv.w; g.y = d_qkv_;
+    g.x = d_x_; g.ldx = H; g.gain = L.in_norm.g; g.eps = c.llm_rms_eps; gemv_w(g, L.qkv); g.y = d_qkv_;
     g.ldy = 3 * H; g.B = B; g.N = 3 * H; g.K = H;
     launch_gemv<T>(g, s);
     T* qk = (keep_q && i == nl - 1) ? q_last_ : nullptr;
@@ -902,14 +967,14 @@ void Model<T>::llm_decode_step(hipStream_t s, int B, bool keep_q) {
       launch_attention<T>(a, s);
     }
     GemvArgs o;
-    o.x = d_att_; o.ldx = H; o.W = L.o.w; o.y = d_x_; o.resid = d_x_; o.ldy = H; o.B = B; o.N = H; o.K = H;
+    o.x = d_att_; o.ldx = H; gemv_w(o, L.o); o.y = d_x_; o.resid = d_x_; o.ldy = H; o.B = B; o.N = H; o.K = H;
     launch_gemv<T>(o, s);
     GemvArgs m;
-    m.x = d_x_; m.ldx = H; m.gain = L.post_norm.g; m.eps = c.llm_rms_eps; m.W = L.gate_w; m.W2 = L.up_w;
+    m.x = d_x_; m.ldx = H; m.gain = L.post_norm.g; m.eps = c.llm_rms_eps; gemv_w(m, L.gu, 0); gemv_w2(m, L.gu, F);
     m.y = d_act_; m.ldy = F; m.B = B; m.N = F; m.K = H;
     launch_gemv<T>(m, s);
     GemvArgs d;
-    d.x = d_act_; d.ldx = F; d.W = L.down.w; d.y = d_x_; d.resid = d_x_; d.ldy = H; d.B = B; d.N = H; d.K = F;
+    d.x = d_act_; d.ldx = F; gemv_w(d, L.down); d.y = d_x_; d.resid = d_x_; d.ldy = H; d.B = B; d.N = H; d.K = F;
     launch_gemv<T>(d, s);
   }
   NormArgs n;
@@ -917,7 +982,7 @@ void Model<T>::llm_decode_step(hipStream_t s, int B, bool keep_q) {
   n.eps = c.llm_rms_eps; n.rms = 1; n.y_f32 = 1; n.row_map = rowmap_dev_;
   launch_norm<T>(n, s);
   GemvArgs h;
-  h.x = d_x_; h.ldx = H; h.gain = llm_norm_.g; h.eps = c.llm_rms_eps; h.W = lm_head_.w; h.y = l_logits_;
+  h.x = d_x_; h.ldx = H; h.gain = llm_norm_.g; h.eps = c.llm_rms_eps; gemv_w(h, lm_head_); h.y = l_logits_;
   h.ldy = c.llm_vocab; h.B = B; h.N = c.llm_vocab; h.K = H;
   launch_gemv<T>(h, s);
   launch_argmax(l_logits_, B, c.llm_vocab, c.llm_vocab, next_dev_, s, pos_dev_);  // and pos += 1
@@ -1302,7 +1367,7 @@ void Model<T>::generate(hipStream_t s, const float* clip_images, const float* sa
     HIP_TRY(hipStreamSynchronize(s));
     launch_gather_rows(hidden_all_, S, H, idx_a_, idx_b_, B, l_xlast_, s);
     GemvArgs h;
-    h.x = l_xlast_; h.ldx = H; h.W = lm_head_.w; h.y = l_logits_; h.ldy = c.llm_vocab; h.B = B; h.N = c.llm_vocab;
+    h.x = l_xlast_; h.ldx = H; gemv_w(h, lm_head_); h.y = l_logits_; h.ldy = c.llm_vocab; h.B = B; h.N = c.llm_vocab;
     h.K = H;
     launch_gemv<T>(h, s);
     launch_argmax(l_logits_, B, c.llm_vocab, c.llm_vocab, next_dev_, s);
@@ -1396,7 +1461,8 @@ void Model<T>::forward_teacher(hipStream_t s, const float* clip_images, const fl
 
 std::unique_ptr<ModelBase> make_model(const anyref_config& cfg, int device) {
   if (cfg.mode == ANYREF_MODE_PARITY) return std::unique_ptr<ModelBase>(new Model<float>(cfg, device));
-  if (cfg.mode == ANYREF_MODE_PERF) return std::unique_ptr<ModelBase>(new Model<bf16>(cfg, device));
+  if (cfg.mode == ANYREF_MODE_PERF || cfg.mode == ANYREF_MODE_PERF_FP8W)
+    return std::unique_ptr<ModelBase>(new Model<bf16>(cfg, device));
   throw std::runtime_error("unknown mode");
 }
 

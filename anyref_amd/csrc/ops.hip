@@ -936,4 +936,64 @@ void launch_sam_preprocess(const uint8_t* img, int h, int w, int S, const float*
                      mean[0], mean[1], mean[2], std_[0], std_[1], std_[2], out);
 }
 
+// ---------------------------------------------------------------------------------------------
+// fp8 weight-only quantisation (BASELINE config 5: 13B LLM, fp8 weights).  One workgroup per row.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void quant_fp8_rows_kernel(const float* __restrict__ src, int lds, int K,
+                                                             uint8_t* __restrict__ q, int ldq,
+                                                             float* __restrict__ scale) {
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const float* row = src + (int64_t)n * lds;
+  float amax = 0.f;
+  for (int k = tid; k < K; k += 256) amax = fmaxf(amax, fabsf(row[k]));
+  amax = wave_max(amax);
+  __shared__ float red[4];
+  if ((tid & 63) == 0) red[tid >> 6] = amax;
+  __syncthreads();
+  amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  const float sc = amax > 0.f ? amax / FP8_E4M3_MAX : 1.f;
+  if (tid == 0) scale[n] = sc;
+  uint8_t* out = q + (int64_t)n * ldq;
+  for (int k = tid * 2; k < K; k += 512) {  // two values per v_cvt_pk_fp8_f32 (RNE, saturating)
+    const float a = row[k] / sc, b = k + 1 < K ? row[k + 1] / sc : 0.f;
+    const int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    out[k] = (uint8_t)(w & 255);
+    if (k + 1 < K) out[k + 1] = (uint8_t)((w >> 8) & 255);
+  }
+}
+void launch_quant_fp8_rows(const float* src, int lds, int N, int K, uint8_t* q, int ldq, float* scale, hipStream_t s) {
+  if (N <= 0) return;
+  hipLaunchKernelGGL(quant_fp8_rows_kernel, dim3(N), dim3(256), 0, s, src, lds, K, q, ldq, scale);
+}
+
+__global__ __launch_bounds__(256) void dequant_fp8_rows_kernel(const uint8_t* __restrict__ q, int ldq,
+                                                               const float* __restrict__ scale, int N, int K,
+                                                               bf16* __restrict__ out, int ldo) {
+  // 16 values per thread step: one 16-byte load, two 16-byte stores
+  const int64_t per_row = K / 16;
+  const int64_t total = (int64_t)N * per_row;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int n = (int)(i / per_row), c = (int)(i % per_row);
+    const uint4v v = *reinterpret_cast<const uint4v*>(q + (int64_t)n * ldq + c * 16);
+    float f[16];
+    unpack_fp8x16(v, f);
+    const float sc = scale[n];
+    uint32_t w[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w[j] = (uint32_t)f2bf(f[2 * j] * sc).x | ((uint32_t)f2bf(f[2 * j + 1] * sc).x << 16);
+    uint4v* o = reinterpret_cast<uint4v*>(out + (int64_t)n * ldo + c * 16);
+    o[0] = uint4v{w[0], w[1], w[2], w[3]};
+    o[1] = uint4v{w[4], w[5], w[6], w[7]};
+  }
+}
+void launch_dequant_fp8_rows(const uint8_t* q, int ldq, const float* scale, int N, int K, void* out_bf16, int ldo,
+                             hipStream_t s) {
+  if (N <= 0) return;
+  if (K % 16 || ldq % 16 || ldo % 8) throw std::runtime_error("dequant_fp8: K must be a multiple of 16");
+  int64_t blocks = cdiv64((int64_t)N * (K / 16), 256);
+  blocks = blocks > 4096 ? 4096 : blocks;
+  hipLaunchKernelGGL(dequant_fp8_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, s, q, ldq, scale, N, K,
+                     reinterpret_cast<bf16*>(out_bf16), ldo);
+}
+
 }  // namespace anyref

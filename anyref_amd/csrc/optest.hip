@@ -87,6 +87,21 @@ int anyref_op_postprocess(void* stream, const float* low, int n, int lh, int lw,
   OP_GUARD(launch_postprocess(low, (int64_t)lh * lw, n, lh, lw, S, rh, rw, H, W, out, (hipStream_t)stream));
 }
 
+int anyref_op_quant_fp8(void* stream, const float* src, int N, int K, uint8_t* q, float* scale) {
+  OP_GUARD(launch_quant_fp8_rows(src, K, N, K, q, K, scale, (hipStream_t)stream));
+}
+
+int anyref_op_gemv_fp8(void* stream, const float* x, const float* gain, float eps, const uint8_t* W,
+                       const uint8_t* W2, const float* scale, const float* scale2, float* y, const float* resid,
+                       int B, int N, int K) {
+  OP_GUARD({
+    GemvArgs a;
+    a.x = x; a.ldx = K; a.gain = gain; a.eps = eps; a.W = W; a.W2 = W2; a.wscale = scale; a.wscale2 = scale2;
+    a.w_fp8 = 1; a.y = y; a.resid = resid; a.ldy = N; a.B = B; a.N = N; a.K = K;
+    launch_gemv<bf16>(a, (hipStream_t)stream);
+  });
+}
+
 int anyref_op_iou_counts(void* stream, const float* logits, const uint8_t* target, int n, int64_t hw,
                          int64_t* counts) {
   OP_GUARD(launch_iou_counts(logits, target, n, hw, counts, (hipStream_t)stream));

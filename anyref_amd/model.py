@@ -76,7 +76,7 @@ class AnyRefForCausalLM:
         self.dice_loss_weight = kwargs.pop("dice_loss_weight", 0.5)
         self.bce_loss_weight = kwargs.pop("bce_loss_weight", 2.0)
         self.cfg = cfg
-        self.mode = {"parity": _lib.MODE_PARITY, "perf": _lib.MODE_PERF}[mode]
+        self.mode = {"parity": _lib.MODE_PARITY, "perf": _lib.MODE_PERF, "perf_fp8w": _lib.MODE_PERF_FP8W}[mode]
         self.mode_name = mode
         self.device_index = device
         self.device = torch.device("cuda", device)

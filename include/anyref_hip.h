@@ -34,6 +34,10 @@ extern "C" {
 /* compute modes */
 #define ANYREF_MODE_PARITY 0 /* fp32 activations + fp32-input MFMA (exact fp32 accumulate) */
 #define ANYREF_MODE_PERF 1   /* bf16 weights/activations on bf16 MFMA, fp32 accumulate + fp32 residual stream */
+/* PERF with the LLaMA linear layers (q/k/v/o, gate/up/down, lm_head) held as fp8 e4m3 bytes + one f32 scale
+ * per output row (weight-only, quantised at finalize: scale = max|row| / 448, RNE): half the weight bytes of
+ * the HBM-bound decode; activations, the vision towers and SAM stay as in PERF (BASELINE config 5) */
+#define ANYREF_MODE_PERF_FP8W 2
 
 typedef struct anyref_config {
   int32_t abi_version; /* = ANYREF_ABI_VERSION */

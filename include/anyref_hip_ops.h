@@ -28,6 +28,12 @@ int anyref_op_attention(int t, void* stream, const void* q, const void* k, const
 /* SAM decomposed rel-pos tables from q [B,S=size*size,H,hd] (type t) */
 int anyref_op_rel_pos(int t, void* stream, const void* q, const float* tab_h, const float* tab_w, int B, int H,
                       int size, int hd, float* rel_h, float* rel_w);
+/* Row-wise fp8 e4m3 quantisation used by ANYREF_MODE_PERF_FP8W: src f32 [N,K] -> q u8 [N,K], scale f32 [N] */
+int anyref_op_quant_fp8(void* stream, const float* src, int N, int K, uint8_t* q, float* scale);
+/* decode GEMV on fp8 weights: y[b,n] = (sum_k bf16(norm(x))[b,k] * q[n,k]) * scale[n] (SwiGLU pair if W2) */
+int anyref_op_gemv_fp8(void* stream, const float* x, const float* gain, float eps, const uint8_t* W,
+                       const uint8_t* W2, const float* scale, const float* scale2, float* y, const float* resid,
+                       int B, int N, int K);
 /* SURVEY.md §8 f-2, replaces `(torch.sigmoid(pred) > 0.5).int()` + utils/utils.py:79-91
  * intersectionAndUnionGPU(pred, gt, 2, ignore_index=255) (call site eval_referseg.py:189-208):
  * logits f32 [n, hw] (device), target u8 [n, hw] with values 0 / 1 / 255 (device), counts i64 [n, 6]

@@ -1,0 +1,97 @@
+"""BASELINE config 5's arithmetic (fp8 weight-only LLM path) at test size: the quantiser is bit-exact against
+its torch statement, the fp8 GEMV matches a torch reference on the dequantised weights, and the whole
+generate() agrees with the oracle run on those same dequantised weights."""
+import ctypes as C
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from anyref_amd import _lib  # noqa: E402
+from anyref_amd.config import config_tiny  # noqa: E402
+from anyref_amd.quant import dequantize_rows_fp8, dequantized_state_dict, is_fp8_weight, quantize_rows_fp8  # noqa: E402
+from anyref_amd.synth import synth_state_dict  # noqa: E402
+from oracle import anyref_oracle as O  # noqa: E402
+from test_gpu_e2e import make_inputs, rig_seg  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+
+
+@pytest.mark.parametrize("N,K", [(64, 256), (33, 688), (7, 16), (128, 4096)])
+def test_quantiser_bit_exact(N, K):
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(N * K)
+    w = torch.randn(N, K, generator=g) * 0.02
+    w[0, :] = 0                      # all-zero row -> scale 1
+    w[1, 0] = 3.0                    # a row dominated by one outlier: most values land in the subnormals
+    w[2, :8] = torch.tensor([1e-9, -1e-9, 5e-5, -5e-5, 0.02, -0.02, 1e-3, 7e-4])
+    wd = w.cuda()
+    q = torch.empty(N, K, dtype=torch.uint8, device="cuda")
+    s = torch.empty(N, dtype=torch.float32, device="cuda")
+    assert lib.anyref_op_quant_fp8(None, P(wd), N, K, P(q), P(s)) == 0, lib.anyref_op_last_error()
+    torch.cuda.synchronize()
+    q_ref, s_ref = quantize_rows_fp8(w)
+    assert torch.equal(s.cpu(), s_ref)
+    # -0 and +0 are the same value; compare the decoded numbers and the bytes away from zero
+    assert torch.equal(dequantize_rows_fp8(q.cpu(), s.cpu()), dequantize_rows_fp8(q_ref, s_ref))
+    nz = (q_ref & 0x7F) != 0
+    assert torch.equal(q.cpu()[nz], q_ref[nz])
+
+
+@pytest.mark.parametrize("B,N,K,dual,norm", [(1, 512, 256, False, True), (2, 96, 688, False, False),
+                                              (1, 688, 256, True, True), (4, 40, 4096, False, True)])
+def test_gemv_fp8_vs_torch(B, N, K, dual, norm):
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(B * N + K)
+    w = torch.randn(N, K, generator=g) * 0.03
+    w2 = torch.randn(N, K, generator=g) * 0.03
+    x = torch.randn(B, K, generator=g)
+    gain = torch.rand(K, generator=g) + 0.5
+    q, s = quantize_rows_fp8(w)
+    q2, s2 = quantize_rows_fp8(w2)
+    xn = x * torch.rsqrt((x * x).mean(-1, keepdim=True) + 1e-6) * gain if norm else x
+    xb = xn.bfloat16().float()                                     # activations are staged as bf16
+    ref = xb @ dequantize_rows_fp8(q, s).T
+    if dual:
+        ref = torch.nn.functional.silu(ref) * (xb @ dequantize_rows_fp8(q2, s2).T)
+    y = torch.empty(B, N, device="cuda")
+    keep = [x.cuda(), gain.cuda(), q.cuda(), q2.cuda(), s.cuda(), s2.cuda()]
+    rc = lib.anyref_op_gemv_fp8(None, P(keep[0]), P(keep[1]) if norm else None, 1e-6, P(keep[2]),
+                                P(keep[3]) if dual else None, P(keep[4]), P(keep[5]) if dual else None, P(y), None, B, N, K)
+    assert rc == 0, lib.anyref_op_last_error()
+    torch.cuda.synchronize()
+    err = (y.cpu() - ref).abs().max().item()
+    assert err < 2e-4 * max(1.0, ref.abs().max().item()), err
+
+
+def test_generate_fp8w_matches_oracle_on_dequantised_weights():
+    from anyref_amd.model import AnyRefForCausalLM
+    cfg = config_tiny()
+    sd = synth_state_dict(cfg, seed=3, scale=0.05)
+    sd_dq = dequantized_state_dict(sd)
+    assert any(is_fp8_weight(k) for k in sd) and not is_fp8_weight("model.embed_tokens.weight")
+    clip, sam, ids = make_inputs(cfg, 1, seed=4)
+    sizes, H, W = [(224, 180)], [300], [241]
+    rig_seg(cfg, sd_dq, clip, sam, ids, sizes, (H, W))
+    with torch.no_grad():
+        ref = O.anyref_generate(sd_dq, cfg, clip, ids, sam, sizes, H, W, max_new_tokens=6, eos=False)
+    assert ref["pred_masks"] is not None
+    m = AnyRefForCausalLM.from_state_dict(cfg, {k: v.cuda() for k, v in sd.items()}, mode="perf_fp8w", max_batch=1, max_seg=4)
+    m.config.eos_token_id = None
+    (out_ids, masks, _), ex = m.generate(clip, ids[0][None], sam, sizes, H, W, max_new_tokens=6, _return_extras=True)
+    n = ref["hidden"][0].shape[0]
+    herr = (ex["hidden"][0, :n].cpu() - ref["hidden"][0]).abs().max().item()
+    assert herr < 0.15, f"hidden err {herr}"                      # the bf16 perf-mode bound (test_gpu_e2e)
+    if out_ids[0].cpu().tolist() == ref["output_ids"][0].tolist():
+        err = (masks[0].cpu() - ref["pred_masks"][0]).abs().max().item()
+        assert err <= 5e-2, err
+    # the fp8 model is NOT the bf16 model: same call on the original weights differs
+    m2 = AnyRefForCausalLM.from_state_dict(cfg, {k: v.cuda() for k, v in sd.items()}, mode="perf", max_batch=1, max_seg=4)
+    m2.config.eos_token_id = None
+    (_, _, _), ex2 = m2.generate(clip, ids[0][None], sam, sizes, H, W, max_new_tokens=6, _return_extras=True)
+    assert (ex2["hidden"][0, :n] - ex["hidden"][0, :n]).abs().max().item() > 1e-3
+    assert m.device_bytes < m2.device_bytes
