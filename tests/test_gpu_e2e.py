@@ -186,3 +186,36 @@ def test_decode_launch_modes_bit_identical(mode, B):
                 assert torch.equal(cur[1], ref[1]), f"hidden states differ ({tag})"
                 for a, b in zip(cur[2], ref[2]):
                     assert (a is None) == (b is None) and (a is None or torch.equal(a, b)), f"masks differ ({tag})"
+
+
+def test_limits_and_error_paths():
+    """Maximum sizes and refusals: the sequence budget, the batch budget, the [SEG] budget, one new token,
+    several [SEG] tokens in one image, and that a failed call leaves the handle usable."""
+    from anyref_amd.model import AnyRefForCausalLM
+    cfg = config_tiny()
+    cfg.llm.max_seq = 288                      # 255 image tokens + 16 prompt tokens + 17 to spare
+    sd = synth_state_dict(cfg, seed=11, scale=0.05)
+    clip, sam, ids = make_inputs(cfg, 2, seed=12)
+    sizes, H, W = [(224, 224)] * 2, [224] * 2, [224] * 2
+    m = AnyRefForCausalLM.from_state_dict(cfg, {k: v.cuda() for k, v in sd.items()}, mode="parity", max_batch=1, max_seg=2)
+    m.config.eos_token_id = None
+    one = (clip[:1], ids[0][None], sam[:1], sizes[:1], H[:1], W[:1])
+    # exactly at the sequence limit: 271 spliced tokens + 17 new ones = 288
+    o, _, _ = m.generate(*one, max_new_tokens=17)
+    assert o.shape[1] == len(ids[0]) + 17
+    with pytest.raises(RuntimeError, match="max_seq"):
+        m.generate(*one, max_new_tokens=18)
+    with pytest.raises(ValueError, match="max_batch"):
+        m.generate(clip, pad(ids)[0], sam, sizes, H, W, max_new_tokens=2)
+    with pytest.raises(RuntimeError):
+        m.generate(*one, max_new_tokens=0)
+    # the handle still works after the refusals, and one new token is a valid (prefill-only) call
+    o1, masks1, _ = m.generate(*one, max_new_tokens=1)
+    assert o1.shape[1] == len(ids[0]) + 1 and torch.equal(o1[0, :-1].cpu(), ids[0]) and int(o1[0, -1]) == int(o[0, len(ids[0])])
+    # every id is a [SEG]: more masks in one image than max_seg is refused, and the handle survives that too
+    m.set_seg_token_idx(list(range(0, cfg.llm.vocab)))
+    with pytest.raises(RuntimeError, match="seg"):
+        m.generate(*one, max_new_tokens=6)
+    m.set_seg_token_idx(cfg.llm.vocab + 1)
+    o2, masks2, _ = m.generate(*one, max_new_tokens=17)
+    assert masks2 is None and torch.equal(o2, o)
