@@ -421,6 +421,62 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, int splits
   }
 }
 
+// Split-K reduction of one output ROW per workgroup with the RMSNorm that follows fused in: sums the slabs
+// in a fixed order, applies bias / activation / residual, writes C, then y = C * rsqrt(mean C^2 + eps) * gain
+// as T.  Saves a launch and a pass over x per prefill o_proj / down_proj (N <= 8192).
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_norm_kernel(const float* __restrict__ slabs, int splits,
+                                                                 int64_t slab_stride, GemmArgs a) {
+  constexpr int MAXV = 8;  // float4 per thread: N <= 256 * 4 * 8
+  const int m = blockIdx.x, tid = threadIdx.x, nv = a.N / 4;
+  float* Cf = reinterpret_cast<float*>(a.C);
+  T* Ct = reinterpret_cast<T*>(a.C);
+  float4v v[MAXV];
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = tid + i * 256;
+    if (c < nv) {
+      const int n = c * 4;
+      const int64_t e = (int64_t)m * a.N + n;
+      float4v acc = *reinterpret_cast<const float4v*>(slabs + e);
+      for (int z = 1; z < splits; ++z) acc += *reinterpret_cast<const float4v*>(slabs + z * slab_stride + e);
+      acc *= a.alpha;
+      if (a.bias) acc += *reinterpret_cast<const float4v*>(a.bias + n);
+      acc = float4v{apply_act(acc[0], a.act), apply_act(acc[1], a.act), apply_act(acc[2], a.act), apply_act(acc[3], a.act)};
+      if (a.resid) acc += *reinterpret_cast<const float4v*>(a.resid + (int64_t)m * a.ldr + n);
+      if (a.c_f32) {
+        *reinterpret_cast<float4v*>(Cf + (int64_t)m * a.ldc + n) = acc;
+      } else {
+        T* o = Ct + (int64_t)m * a.ldc + n;
+        o[0] = from_f32<T>(acc[0]); o[1] = from_f32<T>(acc[1]); o[2] = from_f32<T>(acc[2]); o[3] = from_f32<T>(acc[3]);
+      }
+      v[i] = acc;
+      ss += acc[0] * acc[0] + acc[1] * acc[1] + acc[2] * acc[2] + acc[3] * acc[3];
+    } else {
+      v[i] = float4v{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  ss = wave_sum(ss);
+  __shared__ float red[4];
+  if ((tid & 63) == 0) red[tid >> 6] = ss;
+  __syncthreads();
+  const float scale = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)a.N + a.norm_eps);
+  T* y = reinterpret_cast<T*>(a.norm_out) + (int64_t)m * a.norm_ld;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = tid + i * 256;
+    if (c < nv) {
+      const int n = c * 4;
+      const float4v g = *reinterpret_cast<const float4v*>(a.norm_gain + n);
+      y[n] = from_f32<T>(v[i][0] * scale * g[0]);
+      y[n + 1] = from_f32<T>(v[i][1] * scale * g[1]);
+      y[n + 2] = from_f32<T>(v[i][2] * scale * g[2]);
+      y[n + 3] = from_f32<T>(v[i][3] * scale * g[3]);
+    }
+  }
+}
+
 // per-stream slab workspace (grown on demand; streams never share one)
 static float* splitk_workspace(hipStream_t s, size_t bytes) {
   struct Ws { hipStream_t s; float* p; size_t cap; };
@@ -444,6 +500,7 @@ static float* splitk_workspace(hipStream_t s, size_t bytes) {
 template <typename T>
 void launch_gemm(const GemmArgs& a_in, hipStream_t s) {
   GemmArgs a = a_in;
+  if (a.norm_done) *a.norm_done = false;
   constexpr int VEC = Mma<T>::VEC;
   // ---- split-K decision: few 64x64 tiles, deep K, plain row-major output ----
   if (!getenv("ANYREF_GEMM_NO_SPLITK") && sizeof(T) == 2 && a.batch == 1 && !a.row_map && a.M <= 512 && a.K >= 2048 && a.N % 4 == 0 && a.ldc % 4 == 0 &&
@@ -463,6 +520,11 @@ void launch_gemm(const GemmArgs& a_in, hipStream_t s) {
       g.C = ws; g.ldc = a.N; g.sC = slab; g.c_f32 = 1;
       g.bias = nullptr; g.resid = nullptr; g.act = ACT_NONE; g.alpha = 1.f;
       launch_gemm<T>(g, s);
+      if (a.norm_out && a.norm_gain && a.N <= 8192 && a.norm_ld % 4 == 0) {
+        hipLaunchKernelGGL((splitk_reduce_norm_kernel<T>), dim3(a.M), dim3(256), 0, s, ws, splits, slab, a);
+        if (a.norm_done) *a.norm_done = true;
+        return;
+      }
       const int64_t total = slab / 4;
       const int grid = (int)(cdiv64(total, 256) < 2048 ? cdiv64(total, 256) : 2048);
       hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(grid), dim3(256), 0, s, ws, splits, slab, a);

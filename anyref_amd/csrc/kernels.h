@@ -79,6 +79,13 @@ struct GemmArgs {
   int order = 3;   // bit 0: XCD-chunked block remap, bit 1: M-fastest tile order
   int group_m = 0;  // > 0 (set by the launcher): grouped tile order, this many tile rows per group
   int vec_ok = 0;  // set by the launcher: N / strides / bases allow 4-wide vector epilogue accesses
+  // optional: RMSNorm of the finished output rows fused into the split-K reduction (prefill o_proj /
+  // down_proj -> the norm that follows).  Honoured only on the split-K path; *norm_done says whether it was.
+  const float* norm_gain = nullptr;
+  void* norm_out = nullptr;  // T [M, N], row stride norm_ld
+  int norm_ld = 0;
+  float norm_eps = 0.f;
+  bool* norm_done = nullptr;
   // optional batching over blockIdx.z (element strides)
   int batch = 1;
   int64_t sA = 0, sW = 0, sC = 0, sR = 0, sBias = 0;

@@ -160,9 +160,16 @@ class Model : public ModelBase {
   }
 
   // ---- op helpers ----
-  void gemm(hipStream_t s, const T* A, int lda, const Lin<T>& l, void* C, int ldc, int M, int act, bool c_f32,
-            const float* resid = nullptr, int ldr = 0, const int* row_map = nullptr) {
+  // nrm / nrm_out: RMSNorm (gain nrm->g, llm eps) of the output rows written to nrm_out as T when the GEMM
+  // takes its split-K path; returns whether that happened (else the caller runs the norm itself)
+  bool gemm(hipStream_t s, const T* A, int lda, const Lin<T>& l, void* C, int ldc, int M, int act, bool c_f32,
+            const float* resid = nullptr, int ldr = 0, const int* row_map = nullptr, const Affine* nrm = nullptr,
+            T* nrm_out = nullptr) {
     GemmArgs a;
+    bool fused = false;
+    if (nrm && nrm_out) {
+      a.norm_gain = nrm->g; a.norm_out = nrm_out; a.norm_ld = l.n; a.norm_eps = cfg.llm_rms_eps; a.norm_done = &fused;
+    }
     a.A = A; a.lda = lda; a.W = l.w; a.ldw = l.k; a.bias = l.b; a.C = C; a.ldc = ldc; a.M = M; a.N = l.n;
     a.K = l.k; a.act = act; a.c_f32 = c_f32 ? 1 : 0; a.resid = resid; a.ldr = ldr; a.row_map = row_map;
     if (l.w8) {  // fp8 weights: the M > 16 GEMM multiplies a bf16 image of q * scale (decode streams the bytes)
@@ -170,6 +177,7 @@ class Model : public ModelBase {
       a.W = deq_buf_;
     }
     launch_gemm<T>(a, s);
+    return fused;
   }
   // nn.Linear (or a row range of a fused one) as the weight operand of a decode GEMV
   void gemv_w(GemvArgs& g, const Lin<T>& l, int row0 = 0) const {
@@ -900,11 +908,12 @@ void Model<T>::llm_prefill(hipStream_t s, int B, int Sp, const int* lens_dev, bo
   const anyref_config& c = cfg;
   const int H = c.llm_dim, F = c.llm_mlp, nh = c.llm_heads, hd = H / nh, S = c.llm_max_seq, R = B * Sp;
   const int nl = c.llm_layers;
+  bool h_ready = false;  // l_h_ already holds in_norm(x) (fused into the previous layer's down_proj reduction)
   for (int i = 0; i < nl; ++i) {
     LlmLayer& L = llm_layers_[i];
     T* kc = kcache_ + cache_layer_stride_ * i;
     T* vc = vcache_ + cache_layer_stride_ * i;
-    norm(s, l_x_, H, L.in_norm, l_h_, H, R, H, c.llm_rms_eps, false, true);
+    if (!h_ready) norm(s, l_x_, H, L.in_norm, l_h_, H, R, H, c.llm_rms_eps, false, true);
     gemm(s, l_h_, H, L.qkv, l_qkv_, 3 * H, R, ACT_NONE, false);
     launch_rope_cache<T>(l_qkv_, B, Sp, nh, hd, nullptr, lens_dev, rope_tab_, l_q_, kc, vc, S,
                          (keep_q && i == nl - 1) ? q_last_ : nullptr, s);
@@ -917,11 +926,12 @@ void Model<T>::llm_prefill(hipStream_t s, int B, int Sp, const int* lens_dev, bo
     a.scale = 1.f / sqrtf((float)hd);
     a.causal = 1; a.kv_len = lens_dev; a.q_len = lens_dev;
     launch_attention<T>(a, s);
-    gemm(s, l_att_, H, L.o, l_x_, H, R, ACT_NONE, true, l_x_, H);
-    norm(s, l_x_, H, L.post_norm, l_h_, H, R, H, c.llm_rms_eps, false, true);
+    if (!gemm(s, l_att_, H, L.o, l_x_, H, R, ACT_NONE, true, l_x_, H, nullptr, &L.post_norm, l_h_))
+      norm(s, l_x_, H, L.post_norm, l_h_, H, R, H, c.llm_rms_eps, false, true);
     gemm(s, l_h_, H, L.gu, l_gu_, 2 * F, R, ACT_NONE, false);
     launch_swiglu<T>(l_gu_, R, F, l_act_, s);
-    gemm(s, l_act_, F, L.down, l_x_, H, R, ACT_NONE, true, l_x_, H);
+    h_ready = gemm(s, l_act_, F, L.down, l_x_, H, R, ACT_NONE, true, l_x_, H, nullptr,
+                   i + 1 < nl ? &llm_layers_[i + 1].in_norm : nullptr, l_h_);
   }
   for (int b = 0; b < B; ++b)
     norm(s, l_x_ + (size_t)b * Sp * H, H, llm_norm_, hidden_all_ + (size_t)b * S * H, H, Sp, H, c.llm_rms_eps, true,
