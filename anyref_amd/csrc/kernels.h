@@ -255,6 +255,8 @@ void launch_postprocess(const float* low, int64_t lstride, int n, int lh, int lw
 void launch_dense_pe(const float* gauss, int g, int F, float* out, hipStream_t s);
 void launch_fill_i32(int* p, int v, int n, hipStream_t s);
 void launch_add_i32(int* p, int v, int n, hipStream_t s);
+template <typename T>
+void launch_fill_rows_bias(void* dst, int ld, const int* rows, int nrows, const float* bias, int N, hipStream_t s);
 // SURVEY.md §8 f-2 / f-1 (the steps right after / before the path)
 void launch_iou_counts(const float* logits, const uint8_t* target, int n, int64_t hw, int64_t* counts, hipStream_t s);
 void launch_sam_preprocess(const uint8_t* img, int h, int w, int S, const float* mean, const float* std_, float* out,

@@ -936,6 +936,21 @@ void launch_sam_preprocess(const uint8_t* img, int h, int w, int S, const float*
                      mean[0], mean[1], mean[2], std_[0], std_[1], std_[2], out);
 }
 
+// rows[i] of dst <- bias (SAM window layers: q/k/v of a zero-padded token is exactly the bias)
+template <typename T>
+__global__ __launch_bounds__(256) void fill_rows_bias_kernel(T* __restrict__ dst, int ld, const int* __restrict__ rows,
+                                                             const float* __restrict__ bias, int N) {
+  T* d = dst + (int64_t)rows[blockIdx.x] * ld;
+  for (int n = threadIdx.x; n < N; n += 256) d[n] = from_f32<T>(bias ? bias[n] : 0.f);
+}
+template <typename T>
+void launch_fill_rows_bias(void* dst, int ld, const int* rows, int nrows, const float* bias, int N, hipStream_t s) {
+  if (nrows <= 0) return;
+  hipLaunchKernelGGL((fill_rows_bias_kernel<T>), dim3(nrows), dim3(256), 0, s, reinterpret_cast<T*>(dst), ld, rows, bias, N);
+}
+template void launch_fill_rows_bias<float>(void*, int, const int*, int, const float*, int, hipStream_t);
+template void launch_fill_rows_bias<bf16>(void*, int, const int*, int, const float*, int, hipStream_t);
+
 // ---------------------------------------------------------------------------------------------
 // fp8 weight-only quantisation (BASELINE config 5: 13B LLM, fp8 weights).  One workgroup per row.
 // ---------------------------------------------------------------------------------------------
