@@ -617,8 +617,13 @@ void launch_gemm(const GemmArgs& a_in, hipStream_t s) {
       const double fill256 = (double)t256 / (double)(cdiv64(t256, cus) * cus);
       const int64_t t64w = (int64_t)cdiv(a.M, 64) * cdiv(a.N, 256) * a.batch;
       const int64_t t128 = (int64_t)cdiv(a.M, 128) * cdiv(a.N, 128) * a.batch;
+      using I320 = std::integral_constant<int, 320>;
+      const int64_t t320 = (int64_t)cdiv(a.M, 256) * cdiv(a.N, 320) * a.batch;
+      const double fill320 = (double)t320 / (double)(cdiv64(t320, cus) * cus);
       if (a.M >= 1024 && fill256 >= 0.85)
         go(I256(), I256(), I2(), I4(), I2(), "gemm_bf16_256x256");
+      else if (a.M >= 1024 && a.N % 320 == 0 && fill320 >= 0.95)
+        go(I256(), I320(), I2(), I4(), I2(), "gemm_bf16_256x320");  // SAM fc1: 16 x 16 tiles = one per CU
       else if (a.M <= 512 && a.N >= 8192) {
         if (t64w <= cus) go(I64(), I256(), I1(), I4(), I3(), "gemm_bf16_64x256s3");
         else go(I64(), I256(), I1(), I4(), I2(), "gemm_bf16_64x256");
