@@ -497,13 +497,31 @@ static float* splitk_workspace(hipStream_t s, size_t bytes) {
   return w.p;
 }
 
+// Measurement knobs (read once, scratch/bench_gemm*.py A/B runs; never set in production):
+//   ANYREF_GEMM_NO_GLDS    bf16: use the register-staged kernel instead of the LDS-DMA one
+//   ANYREF_GEMM_NO_SPLITK  never split K
+//   ANYREF_GEMM_GM=n       grouped tile order with n tile rows per group (0: plain M-fastest)
+//   ANYREF_GEMM_TILE=0..3  register-staged kernel: force 64x64 / 64x128 / 128x64 / 128x128
+//   ANYREF_GEMV_GRID=n     decode GEMV workgroups
+struct GemmKnobs {
+  bool no_glds = getenv("ANYREF_GEMM_NO_GLDS") != nullptr;
+  bool no_splitk = getenv("ANYREF_GEMM_NO_SPLITK") != nullptr;
+  int gm = getenv("ANYREF_GEMM_GM") ? atoi(getenv("ANYREF_GEMM_GM")) : -1;
+  int tile = getenv("ANYREF_GEMM_TILE") ? atoi(getenv("ANYREF_GEMM_TILE")) : -1;
+  int gemv_grid = getenv("ANYREF_GEMV_GRID") ? atoi(getenv("ANYREF_GEMV_GRID")) : 0;
+};
+static const GemmKnobs& knobs() {
+  static const GemmKnobs k;
+  return k;
+}
+
 template <typename T>
 void launch_gemm(const GemmArgs& a_in, hipStream_t s) {
   GemmArgs a = a_in;
   if (a.norm_done) *a.norm_done = false;
   constexpr int VEC = Mma<T>::VEC;
   // ---- split-K decision: few 64x64 tiles, deep K, plain row-major output ----
-  if (!getenv("ANYREF_GEMM_NO_SPLITK") && sizeof(T) == 2 && a.batch == 1 && !a.row_map && a.M <= 512 && a.K >= 2048 && a.N % 4 == 0 && a.ldc % 4 == 0 &&
+  if (!knobs().no_splitk && sizeof(T) == 2 && a.batch == 1 && !a.row_map && a.M <= 512 && a.K >= 2048 && a.N % 4 == 0 && a.ldc % 4 == 0 &&
       (!a.resid || a.ldr % 4 == 0)) {
     // 128 x 128 workgroups (two per CU): split until there are ~256 of them, slices of >= 512, multiples of 64
     const int64_t tiles = (int64_t)cdiv(a.M, 128) * cdiv(a.N, 128);
@@ -553,14 +571,13 @@ void launch_gemm(const GemmArgs& a_in, hipStream_t s) {
     bm128 = false;
     bn = t64x128 >= 256 ? 128 : 64;
   }
-  if (const char* fv = getenv("ANYREF_GEMM_TILE")) {  // microbenchmark knob: force a tile variant
-    const int v = atoi(fv);
+  if (knobs().tile >= 0) {
+    const int v = knobs().tile;
     bm128 = v & 2;
     bn = (v & 1) ? 128 : 64;
   }
   dim3 block(256);
-  static const int order_env = getenv("ANYREF_GEMM_ORDER") ? atoi(getenv("ANYREF_GEMM_ORDER")) : 3;
-  a.order = order_env;
+  a.order = 3;
   {
     const int ov = a.c_f32 ? 4 : (int)sizeof(T);  // output element bytes
     const bool al = a.N % 4 == 0 && a.ldc % 4 == 0 && a.sC % 4 == 0 && !((uintptr_t)a.C & 15) &&
@@ -572,8 +589,7 @@ void launch_gemm(const GemmArgs& a_in, hipStream_t s) {
   const double bytes = ((double)a.M * a.K + (double)a.N * a.K) * sizeof(T) * a.batch +
                        (double)a.M * a.N * (a.c_f32 ? 4 : sizeof(T)) * a.batch;
   if constexpr (sizeof(T) == 2) {
-    static const bool glds_off = getenv("ANYREF_GEMM_NO_GLDS") != nullptr;
-    if (!glds_off && a.K % 64 == 0 && !getenv("ANYREF_GEMM_TILE")) {
+    if (!knobs().no_glds && a.K % 64 == 0 && knobs().tile < 0) {
       // Tile choice from scratch/lab/gemm_lab.hip on MI355X: 256^2 when its tiles fill whole rounds of the
       // 256 CUs (SAM qkv: 240 tiles, square 8192^3), 64 x 256 for skinny-M / very wide N (prefill gate/up),
       // otherwise 128^2 with 8 waves (two workgroups per CU).
@@ -588,13 +604,11 @@ void launch_gemm(const GemmArgs& a_in, hipStream_t s) {
                                       (int)lds));
           attr = true;
         }
-        if (getenv("ANYREF_GEMM_DEBUG")) fprintf(stderr, "[gemm] %s M=%d N=%d K=%d batch=%d\n", tag, a.M, a.N, a.K, a.batch);
         {  // rows per group ~ sqrt(tiles one XCD gets), so its chunk is a near-square rectangle
           const int tiles_m = cdiv(a.M, BM), nwg = tiles_m * cdiv(a.N, BN);
           int gm = (int)lround(sqrt((double)(nwg > 8 ? nwg / 8 : 1)));
           gm = gm < 1 ? 1 : (gm > tiles_m ? tiles_m : gm);
-          static const int gm_env = getenv("ANYREF_GEMM_GM") ? atoi(getenv("ANYREF_GEMM_GM")) : -1;
-          a.group_m = gm_env >= 0 ? gm_env : gm;
+          a.group_m = knobs().gm >= 0 ? knobs().gm : gm;
         }
         ProfScope prof(tag, flops, bytes, s);
         dim3 grid(cdiv(a.N, BN) * cdiv(a.M, BM), 1, a.batch);
@@ -874,7 +888,7 @@ static void gemv_dispatch(const GemvArgs& a, int b0, int nb, hipStream_t s) {
   // one or two 8-wave workgroups per CU depending on the LDS the activation stage needs
   // (512 workgroups measured best for N*K of 34-262 MB; 256 / 1024 / 2048 were 3-30 % slower)
   int grid = 256 * (lds > 76 * 1024 ? 1 : 2);
-  if (const char* e = getenv("ANYREF_GEMV_GRID")) grid = atoi(e);  // EXPERIMENT
+  if (knobs().gemv_grid > 0) grid = knobs().gemv_grid;
   auto go = [&](auto xpt_tag) {
     constexpr int XPT = decltype(xpt_tag)::value;
     static bool attr_set = false;  // per instantiation
