@@ -3,9 +3,9 @@
 The reference has no multi-GPU inference at all (single process, batch 1:
 `eval_referseg.py:101-106,255`); images are independent (`anyref.py:797-819`), so the path shards
 as pure DP: one process + one `anyref_handle` per GPU, weights replicated, inputs sharded on the
-host, and ONE collective per call — an all-gather of the low-resolution mask logits
-(`[B_local, max_seg, 4g, 4g]` fp32 = 1 MiB per image at SAM-H) plus a tiny all-gather of the
-token ids / [SEG] counts.  Full-resolution masks are re-created from the gathered low-res logits
+host, and two collectives per call — an all-gather of the low-resolution mask logits
+(`[B_local, max_seg, 4g, 4g]` fp32 = 1 MiB per image at SAM-H) and one of a small int64 record per
+image (token ids, [SEG] count, length).  Full-resolution masks are re-created from the gathered low-res logits
 by the same bilinear postprocess (bit-identical: the resize is per mask), so the 4 MB/mask
 full-res tensors never cross xGMI.  `backend="nccl"` is RCCL on ROCm; the CPU tests drive the
 same code over gloo.
@@ -45,12 +45,17 @@ def gather_results(low: torch.Tensor, nseg: torch.Tensor, ids: torch.Tensor, ids
         pad = torch.zeros((per - t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
         return torch.cat([t, pad], 0).contiguous()
 
-    outs = []
-    for t in (low, nseg, ids, ids_len):
+    # two collectives per call: the low-res logits, and one int64 record per image = [ids | nseg | ids_len]
+    meta = torch.cat([ids.to(torch.int64), nseg.to(torch.int64)[:, None], ids_len.to(torch.int64)[:, None]], 1)
+    gathered = []
+    for t in (low, meta):
         t = padrows(t.cpu() if on_host else t)
         g = torch.empty((world * per,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
         dist.all_gather_into_tensor(g, t, group=group)
-        outs.append(g.to(dev) if on_host else g)
+        gathered.append(g.to(dev) if on_host else g)
+    gm = gathered[1]
+    L = ids.shape[1]
+    outs = [gathered[0], gm[:, L].to(nseg.dtype), gm[:, :L].contiguous(), gm[:, L + 1].to(ids_len.dtype)]
     keep = []
     for r in range(world):
         lo, hi = shard_range(n_global, r, world)
