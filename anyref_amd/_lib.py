@@ -72,6 +72,7 @@ SYMBOLS = {
     "anyref_mode_name": (C.c_char_p, [_P]),
     # kernel-level test entry points (anyref_hip_ops.h)
     "anyref_op_gemm": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I]),
+    "anyref_op_gemm_fp8": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I]),
     "anyref_op_quant_fp8": (_I, [_P, _P, _I, _I, _P, _P]),
     "anyref_op_gemv_fp8": (_I, [_P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _I, _I, _I]),
     "anyref_op_iou_counts": (_I, [_P, _P, _P, _I, _L, _P]),

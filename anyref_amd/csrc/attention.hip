@@ -72,7 +72,6 @@ struct AttnTile {
 // LDS read itself; lane 4q+p supplies the address of row q, columns 4p..4p+3 and lane i receives
 // column i of the 4 rows.  K and V are staged with plain 16-byte row stores.
 // ---------------------------------------------------------------------------------------------
-typedef __attribute__((ext_vector_type(2))) uint32_t uint2v;
 typedef __attribute__((ext_vector_type(4))) short short4v;
 
 // DB transposed 4x16 blocks (consecutive 16-column blocks of the same 4 rows) in ONE asm statement

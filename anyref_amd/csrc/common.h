@@ -62,6 +62,7 @@ __device__ inline bf16 from_f32<bf16>(float v) {
 typedef __attribute__((ext_vector_type(8))) short short8;   // 8 x bf16 = one MFMA A/B fragment
 typedef __attribute__((ext_vector_type(4))) float float4v;  // MFMA 16x16 accumulator
 typedef __attribute__((ext_vector_type(4))) uint32_t uint4v;
+typedef __attribute__((ext_vector_type(2))) uint32_t uint2v;
 
 // 16-byte vector of T -> floats.  NB: __builtin_bit_cast applied directly to an ext_vector element
 // (v[i]) reads element 0 for every i on hipcc/ROCm 7.2; always go through a scalar temporary.

@@ -72,6 +72,7 @@ template <typename T, int ACT, bool VEC>
 __device__ __forceinline__ void epi_store4(const GemmArgs& a, const float* bias, const float* resid, float* Cf, T* Ct,
                                            int dm, int n, float4v v) {
   if constexpr (VEC) {  // N % 4 == 0: the four columns are all valid, rows are 16-byte aligned
+    if (a.col_scale) v *= *reinterpret_cast<const float4v*>(a.col_scale + n);  // fp8 weights: per-row scale
     if (bias) v += *reinterpret_cast<const float4v*>(bias + n);
     v = float4v{act_ct<ACT, sizeof(T) == 2>(v[0]), act_ct<ACT, sizeof(T) == 2>(v[1]), act_ct<ACT, sizeof(T) == 2>(v[2]), act_ct<ACT, sizeof(T) == 2>(v[3])};
     if (resid) v += *reinterpret_cast<const float4v*>(resid + (int64_t)dm * a.ldr + n);
@@ -89,6 +90,7 @@ __device__ __forceinline__ void epi_store4(const GemmArgs& a, const float* bias,
     for (int r = 0; r < 4; ++r) {
       if (n + r < a.N) {
         float x = v[r];
+        if (a.col_scale) x *= a.col_scale[n + r];
         if (bias) x += bias[n + r];
         x = act_ct<ACT, sizeof(T) == 2>(x);
         if (resid) x += resid[(int64_t)dm * a.ldr + n + r];
@@ -264,16 +266,34 @@ __device__ __forceinline__ void wait_vmcnt() {
 // NS-2 tiles in flight across it.  NS = 2 (two workgroups per CU for the 128^2 tile) when there are more
 // tiles than CUs; NS = 3 when every workgroup has a CU to itself anyway (skinny-M prefill / CLIP shapes
 // whose W tiles come from HBM: prefill qkv 71 -> 51 us, CLIP fc1 18 -> 12 us with cold weights).
-template <int BM, int BN, int WM, int WN, int NS>
+// W8: the weight operand is fp8 e4m3 bytes (ANYREF_MODE_PERF_FP8W): its tile is DMA'd as bytes (64 B per row,
+// 16 rows per wave instruction, 16-byte chunk c of row r at chunk c ^ ((r >> 2) & 3): conflict-free 8-byte
+// fragment reads), each fragment is widened to bf16 in registers (exact: e4m3 is a subset of bf16) right
+// before the bf16 MFMA, and the per-row scale of the weight multiplies the accumulator column in the epilogue.
+__device__ __forceinline__ short8 fp8x8_to_bf16x8(uint2v r) {
+  short8 o;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const float2v lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)r[h], false);
+    const float2v hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)r[h], true);
+    o[4 * h] = (short)f2bf(lo[0]).x; o[4 * h + 1] = (short)f2bf(lo[1]).x;
+    o[4 * h + 2] = (short)f2bf(hi[0]).x; o[4 * h + 3] = (short)f2bf(hi[1]).x;
+  }
+  return o;
+}
+
+template <int BM, int BN, int WM, int WN, int NS, bool W8 = false>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs a) {
   using T = bf16;
   constexpr int BK = 64, NW = WM * WN;
   constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 16, NI = TN / 16;
-  constexpr int ROWB = BK * 2;             // bytes per tile row
-  constexpr int TILEB = (BM + BN) * ROWB;  // one stage
-  constexpr int RA = BM / (NW * 8), RW = BN / (NW * 8);  // LDS-DMA rounds (8 rows per wave instruction)
+  constexpr int ROWB = BK * 2;             // bytes per A tile row
+  constexpr int WROWB = W8 ? BK : BK * 2;  // bytes per W tile row
+  constexpr int WRPI = W8 ? 16 : 8;        // W rows per wave DMA instruction
+  constexpr int TILEB = BM * ROWB + BN * WROWB;  // one stage
+  constexpr int RA = BM / (NW * 8), RW = BN / (NW * WRPI);  // LDS-DMA rounds
   constexpr int LPT = RA + RW;                           // DMA instructions per lane per tile
-  static_assert(BM % (NW * 8) == 0 && BN % (NW * 8) == 0, "tile rows must split over the waves");
+  static_assert(BM % (NW * 8) == 0 && BN % (NW * WRPI) == 0, "tile rows must split over the waves");
   static_assert(NS >= 2 && NS <= 4 && (NS - 2) * LPT <= 63, "stage count / vmcnt range");
   extern __shared__ __attribute__((aligned(1024))) char smem[];  // the ONLY LDS object (rule: one array)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -302,7 +322,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs a) {
   const int m0 = tm * BM, n0 = tn * BN;
   const int z = blockIdx.z;
   const T* __restrict__ A = reinterpret_cast<const T*>(a.A) + (int64_t)z * a.sA;
-  const T* __restrict__ W = reinterpret_cast<const T*>(a.W) + (int64_t)z * a.sW;
+  using WT = std::conditional_t<W8, uint8_t, T>;
+  const WT* __restrict__ W = reinterpret_cast<const WT*>(a.W) + (int64_t)z * a.sW;
 
   float4v acc[MI][NI];
 #pragma unroll
@@ -313,7 +334,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs a) {
   // rows past M / N fetch the last valid row (never stored); K is a multiple of 64 (launcher)
   const int srow = lane >> 3, sp = lane & 7;
   const T* asrc[RA];
-  const T* wsrc[RW];
+  const WT* wsrc[RW];
 #pragma unroll
   for (int r = 0; r < RA; ++r) {
     const int row = (r * NW + wave) * 8 + srow;
@@ -323,10 +344,17 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs a) {
   }
 #pragma unroll
   for (int r = 0; r < RW; ++r) {
-    const int row = (r * NW + wave) * 8 + srow;
-    int gn = n0 + row;
-    gn = gn < a.N ? gn : a.N - 1;
-    wsrc[r] = W + (int64_t)gn * a.ldw + ((sp ^ ((row >> 1) & 7)) << 3);
+    if constexpr (W8) {
+      const int row = (r * NW + wave) * 16 + (lane >> 2);
+      int gn = n0 + row;
+      gn = gn < a.N ? gn : a.N - 1;
+      wsrc[r] = W + (int64_t)gn * a.ldw + (((lane & 3) ^ ((row >> 2) & 3)) << 4);
+    } else {
+      const int row = (r * NW + wave) * 8 + srow;
+      int gn = n0 + row;
+      gn = gn < a.N ? gn : a.N - 1;
+      wsrc[r] = W + (int64_t)gn * a.ldw + ((sp ^ ((row >> 1) & 7)) << 3);
+    }
   }
   // The stage index is a compile-time constant (loop unrolled by two below): with a runtime index hipcc
   // cannot tell the DMA destination from the buffer being read and puts s_waitcnt vmcnt(0) in front of the
@@ -341,7 +369,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs a) {
 #pragma unroll
     for (int r = 0; r < RW; ++r)
       __builtin_amdgcn_global_load_lds((gas_ptr)(wsrc[r] + t * BK),
-                                       (las_ptr)(base + BM * ROWB + (r * NW + wave) * 8 * ROWB), 16, 0, 0);
+                                       (las_ptr)(base + BM * ROWB + (r * NW + wave) * WRPI * WROWB), 16, 0, 0);
   };
   auto compute = [&](auto buf_c) {
     constexpr int buf = decltype(buf_c)::value;
@@ -359,7 +387,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs a) {
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
         const int row = wc * TN + j * 16 + (lane & 15);
-        bfr[j] = *reinterpret_cast<const short8*>(Wb + row * ROWB + ((c ^ ((row >> 1) & 7)) << 4));
+        if constexpr (W8) {
+          // k = 32 ks + 8 g .. + 7: the 8 bytes at chunk (2 ks + g / 2), half (g & 1) of the 64-byte row
+          const int g = lane >> 4, c8 = ks * 2 + (g >> 1);
+          bfr[j] = fp8x8_to_bf16x8(
+              *reinterpret_cast<const uint2v*>(Wb + row * WROWB + ((c8 ^ ((row >> 2) & 3)) << 4) + ((g & 1) << 3)));
+        } else {
+          bfr[j] = *reinterpret_cast<const short8*>(Wb + row * ROWB + ((c ^ ((row >> 1) & 7)) << 4));
+        }
       }
 #pragma unroll
       for (int i = 0; i < MI; ++i)
@@ -409,6 +444,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, int splits
     float4v acc = *reinterpret_cast<const float4v*>(slabs + e);
     for (int z = 1; z < splits; ++z) acc += *reinterpret_cast<const float4v*>(slabs + z * slab_stride + e);
     acc *= a.alpha;
+    if (a.col_scale) acc *= *reinterpret_cast<const float4v*>(a.col_scale + n);
     if (a.bias) acc += *reinterpret_cast<const float4v*>(a.bias + n);
     acc = float4v{apply_act(acc[0], a.act), apply_act(acc[1], a.act), apply_act(acc[2], a.act), apply_act(acc[3], a.act)};
     if (a.resid) acc += *reinterpret_cast<const float4v*>(a.resid + (int64_t)m * a.ldr + n);
@@ -442,6 +478,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_norm_kernel(const float* __
       float4v acc = *reinterpret_cast<const float4v*>(slabs + e);
       for (int z = 1; z < splits; ++z) acc += *reinterpret_cast<const float4v*>(slabs + z * slab_stride + e);
       acc *= a.alpha;
+      if (a.col_scale) acc *= *reinterpret_cast<const float4v*>(a.col_scale + n);
       if (a.bias) acc += *reinterpret_cast<const float4v*>(a.bias + n);
       acc = float4v{apply_act(acc[0], a.act), apply_act(acc[1], a.act), apply_act(acc[2], a.act), apply_act(acc[3], a.act)};
       if (a.resid) acc += *reinterpret_cast<const float4v*>(a.resid + (int64_t)m * a.ldr + n);
@@ -536,7 +573,7 @@ void launch_gemm(const GemmArgs& a_in, hipStream_t s) {
       g.sA = g.K;   // column offset inside the same rows
       g.sW = g.K;
       g.C = ws; g.ldc = a.N; g.sC = slab; g.c_f32 = 1;
-      g.bias = nullptr; g.resid = nullptr; g.act = ACT_NONE; g.alpha = 1.f;
+      g.bias = nullptr; g.resid = nullptr; g.act = ACT_NONE; g.alpha = 1.f; g.col_scale = nullptr;
       launch_gemm<T>(g, s);
       if (a.norm_out && a.norm_gain && a.N <= 8192 && a.norm_ld % 4 == 0) {
         hipLaunchKernelGGL((splitk_reduce_norm_kernel<T>), dim3(a.M), dim3(256), 0, s, ws, splits, slab, a);
@@ -588,6 +625,8 @@ void launch_gemm(const GemmArgs& a_in, hipStream_t s) {
   const double flops = 2.0 * a.M * a.N * (double)a.K * a.batch;
   const double bytes = ((double)a.M * a.K + (double)a.N * a.K) * sizeof(T) * a.batch +
                        (double)a.M * a.N * (a.c_f32 ? 4 : sizeof(T)) * a.batch;
+  if (a.w_fp8 && (sizeof(T) != 2 || a.K % 64 || knobs().no_glds || knobs().tile >= 0))
+    throw std::runtime_error("gemm: an fp8 weight operand needs the bf16 LDS-DMA kernel (K % 64 == 0)");
   if constexpr (sizeof(T) == 2) {
     if (!knobs().no_glds && a.K % 64 == 0 && knobs().tile < 0) {
       // Tile choice from scratch/lab/gemm_lab.hip on MI355X: 256^2 when its tiles fill whole rounds of the
@@ -597,6 +636,26 @@ void launch_gemm(const GemmArgs& a_in, hipStream_t s) {
         constexpr int BM = decltype(bm_t)::value, BN = decltype(bn_t)::value, WM = decltype(wm_t)::value,
                       WN = decltype(wn_t)::value, NS = decltype(ns_t)::value;
         constexpr size_t lds = NS * (size_t)(BM + BN) * 128;
+        if constexpr (BN % (WM * WN * 16) == 0) {
+          if (a.w_fp8) {  // fp8 weight operand (LDS of the full-width kernel is an upper bound)
+            auto kern8 = &gemm_glds_kernel<BM, BN, WM, WN, NS, true>;
+            static bool attr8 = false;
+            if (!attr8) {
+              HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern8),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+              attr8 = true;
+            }
+            const int tiles_m8 = cdiv(a.M, BM), nwg8 = tiles_m8 * cdiv(a.N, BN);
+            int gm8 = (int)lround(sqrt((double)(nwg8 > 8 ? nwg8 / 8 : 1)));
+            a.group_m = gm8 < 1 ? 1 : (gm8 > tiles_m8 ? tiles_m8 : gm8);
+            char tag8[48];
+            snprintf(tag8, sizeof(tag8), "%s_fp8w", tag);
+            ProfScope prof(tag8, flops, bytes, s);
+            hipLaunchKernelGGL(kern8, dim3(nwg8, 1, a.batch), dim3(WM * WN * 64), NS * ((size_t)BM * 128 + (size_t)BN * 64),
+                               s, a);
+            return;
+          }
+        }
         auto kern = &gemm_glds_kernel<BM, BN, WM, WN, NS>;
         static bool attr = false;
         if (!attr) {
@@ -636,7 +695,7 @@ void launch_gemm(const GemmArgs& a_in, hipStream_t s) {
       const double fill320 = (double)t320 / (double)(cdiv64(t320, cus) * cus);
       if (a.M >= 1024 && fill256 >= 0.85)
         go(I256(), I256(), I2(), I4(), I2(), "gemm_bf16_256x256");
-      else if (a.M >= 1024 && a.N % 320 == 0 && fill320 >= 0.95)
+      else if (!a.w_fp8 && a.M >= 1024 && a.N % 320 == 0 && fill320 >= 0.95)
         go(I256(), I320(), I2(), I4(), I2(), "gemm_bf16_256x320");  // SAM fc1: 16 x 16 tiles = one per CU
       else if (a.M <= 512 && a.N >= 8192) {
         if (t64w <= cus) go(I64(), I256(), I1(), I4(), I3(), "gemm_bf16_64x256s3");

@@ -77,6 +77,10 @@ struct GemmArgs {
   int c_f32 = 0;  // 1: C is f32, 0: C is T
   float alpha = 1.f;
   int order = 3;   // bit 0: XCD-chunked block remap, bit 1: M-fastest tile order
+  // fp8 weight operand (bf16 LDS-DMA kernel only): W holds e4m3 bytes [N, K] (ldw, sW in bytes), the finished
+  // column n is multiplied by col_scale[n]
+  int w_fp8 = 0;
+  const float* col_scale = nullptr;
   int group_m = 0;  // > 0 (set by the launcher): grouped tile order, this many tile rows per group
   int vec_ok = 0;  // set by the launcher: N / strides / bases allow 4-wide vector epilogue accesses
   // optional: RMSNorm of the finished output rows fused into the split-K reduction (prefill o_proj /

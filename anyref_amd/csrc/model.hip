@@ -172,9 +172,13 @@ class Model : public ModelBase {
     }
     a.A = A; a.lda = lda; a.W = l.w; a.ldw = l.k; a.bias = l.b; a.C = C; a.ldc = ldc; a.M = M; a.N = l.n;
     a.K = l.k; a.act = act; a.c_f32 = c_f32 ? 1 : 0; a.resid = resid; a.ldr = ldr; a.row_map = row_map;
-    if (l.w8) {  // fp8 weights: the M > 16 GEMM multiplies a bf16 image of q * scale (decode streams the bytes)
-      launch_dequant_fp8_rows(l.w8, l.k, l.ws, l.n, l.k, deq_buf_, l.k, s);
-      a.W = deq_buf_;
+    if (l.w8) {
+      if (l.k % 64 == 0) {  // fp8 bytes straight into the GEMM (widened to bf16 per fragment, scale in the epilogue)
+        a.W = l.w8; a.w_fp8 = 1; a.col_scale = l.ws;
+      } else {              // odd K: multiply a bf16 image of q * scale
+        launch_dequant_fp8_rows(l.w8, l.k, l.ws, l.n, l.k, deq_buf_, l.k, s);
+        a.W = deq_buf_;
+      }
     }
     launch_gemm<T>(a, s);
     return fused;

@@ -87,6 +87,16 @@ int anyref_op_postprocess(void* stream, const float* low, int n, int lh, int lw,
   OP_GUARD(launch_postprocess(low, (int64_t)lh * lw, n, lh, lw, S, rh, rw, H, W, out, (hipStream_t)stream));
 }
 
+int anyref_op_gemm_fp8(void* stream, const void* A, const uint8_t* W8, const float* scale, const float* bias, void* C,
+                       const float* resid, int M, int N, int K, int act, int c_f32) {
+  OP_GUARD({
+    GemmArgs a;
+    a.A = A; a.lda = K; a.W = W8; a.ldw = K; a.w_fp8 = 1; a.col_scale = scale; a.bias = bias; a.C = C; a.ldc = N;
+    a.resid = resid; a.ldr = N; a.M = M; a.N = N; a.K = K; a.act = act; a.c_f32 = c_f32;
+    launch_gemm<bf16>(a, (hipStream_t)stream);
+  });
+}
+
 int anyref_op_quant_fp8(void* stream, const float* src, int N, int K, uint8_t* q, float* scale) {
   OP_GUARD(launch_quant_fp8_rows(src, K, N, K, q, K, scale, (hipStream_t)stream));
 }

@@ -30,6 +30,9 @@ int anyref_op_rel_pos(int t, void* stream, const void* q, const float* tab_h, co
                       int size, int hd, float* rel_h, float* rel_w);
 /* Row-wise fp8 e4m3 quantisation used by ANYREF_MODE_PERF_FP8W: src f32 [N,K] -> q u8 [N,K], scale f32 [N] */
 int anyref_op_quant_fp8(void* stream, const float* src, int N, int K, uint8_t* q, float* scale);
+/* bf16 GEMM with an fp8 weight operand: C = act((A W8^T) * scale[n] + bias) (+ resid); A bf16 [M,K], W8 u8 [N,K] */
+int anyref_op_gemm_fp8(void* stream, const void* A, const uint8_t* W8, const float* scale, const float* bias, void* C,
+                       const float* resid, int M, int N, int K, int act, int c_f32);
 /* decode GEMV on fp8 weights: y[b,n] = (sum_k bf16(norm(x))[b,k] * q[n,k]) * scale[n] (SwiGLU pair if W2) */
 int anyref_op_gemv_fp8(void* stream, const float* x, const float* gain, float eps, const uint8_t* W,
                        const uint8_t* W2, const float* scale, const float* scale2, float* y, const float* resid,

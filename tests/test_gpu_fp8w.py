@@ -68,6 +68,29 @@ def test_gemv_fp8_vs_torch(B, N, K, dual, norm):
     assert err < 2e-4 * max(1.0, ref.abs().max().item()), err
 
 
+@pytest.mark.parametrize("M,N,K", [(320, 512, 256),        # 128^2 tile, 3 stages
+                                    (2048, 2048, 512),     # 256^2 tile
+                                    (300, 8200, 128),      # 64 x 256 tile, ragged edges
+                                    (320, 1024, 4096),     # split-K slices + reduction with the scale
+                                    (1500, 700, 192)])     # many 128^2 tiles, ragged N
+def test_gemm_fp8_operand_vs_torch(M, N, K):
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(M + N + K)
+    A = (torch.randn(M, K, generator=g)).bfloat16()
+    w = torch.randn(N, K, generator=g) * 0.03
+    bias = torch.randn(N, generator=g) * 0.1
+    resid = torch.randn(M, N, generator=g)
+    q, s = quantize_rows_fp8(w)
+    ref = A.float() @ dequantize_rows_fp8(q, s).T + bias + resid
+    keep = [A.cuda(), q.cuda(), s.cuda(), bias.cuda(), resid.cuda()]
+    C32 = torch.empty(M, N, device="cuda")
+    rc = lib.anyref_op_gemm_fp8(None, P(keep[0]), P(keep[1]), P(keep[2]), P(keep[3]), P(C32), P(keep[4]), M, N, K, 0, 1)
+    assert rc == 0, lib.anyref_op_last_error()
+    torch.cuda.synchronize()
+    err = (C32.cpu() - ref).abs().max().item()
+    assert err < 2e-3 * max(1.0, ref.abs().max().item()), err
+
+
 def test_generate_fp8w_matches_oracle_on_dequantised_weights():
     from anyref_amd.model import AnyRefForCausalLM
     cfg = config_tiny()
