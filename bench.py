@@ -59,7 +59,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="c2", choices=["c2", "tiny"])
+    ap.add_argument("--config", default="c2", choices=["c2", "c5", "tiny"],
+                    help="c2: BASELINE configs[1] (the headline); c5: 13B LLM, fp8 weights, batch 8 (configs[4]); tiny: plumbing")
+    ap.add_argument("--mode", default=None, choices=["perf", "perf_fp8w"], help="default: perf (bf16); c5: perf_fp8w")
     ap.add_argument("--batch-per-gpu", type=int, default=1)
     ap.add_argument("--max-new-tokens", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -89,10 +91,19 @@ def main():
     from anyref_amd.parallel import gather_results
 
     B, T = args.batch_per_gpu, args.max_new_tokens
+    mode = args.mode or ("perf_fp8w" if args.config == "c5" else "perf")
     if args.config == "c2":
         cfg = config_7b()
         cfg.llm.max_seq = 512
         S_img = 1024
+    elif args.config == "c5":
+        from anyref_amd.config import config_13b
+        cfg = config_13b()
+        cfg.llm.max_seq = 512
+        S_img = 1024
+        if B == 1:
+            B = 8
+        args.no_cpu_baseline = True      # the 13B fp32 oracle needs ~55 GB and minutes per image: not timed here
     else:
         cfg = config_tiny()
         S_img = cfg.sam.img_size
@@ -101,7 +112,7 @@ def main():
     clip, sam, ids = make_inputs(cfg, B, seed=1 + rank)
     clip, sam = clip.to(dev), sam.to(dev)                                          # resident in HBM
     sizes, H, W = [(S_img, S_img)] * B, [S_img] * B, [S_img] * B
-    model = AnyRefForCausalLM.from_state_dict(cfg, sd, mode="perf", device=local, max_batch=B, max_seg=2)
+    model = AnyRefForCausalLM.from_state_dict(cfg, sd, mode=mode, device=local, max_batch=B, max_seg=2)
     model.config.eos_token_id = None                                               # fixed work: T new tokens
     torch.cuda.synchronize()
     log(f"[bench] weights + perf model ready in {time.time() - t0:.1f}s, {model.device_bytes / 2**30:.1f} GiB on device")
@@ -221,12 +232,17 @@ def main():
         table.items(), key=lambda kv: -kv[1]["ms"])}
 
     res = {
-        "metric": "images/sec (1024^2, 7B LLM+ViT-L+SAM-H)" if args.config == "c2" else "images/sec (tiny plumbing config)",
+        "metric": {"c2": "images/sec (1024^2, 7B LLM+ViT-L+SAM-H)", "c5": "images/sec (1024^2, 13B LLM+ViT-L+SAM-H, fp8 weights)",
+                   "tiny": "images/sec (tiny plumbing config)"}[args.config],
         "value": round(ips, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": ("C2: LLaVA-7B + CLIP ViT-L/14 + SAM-H refer-seg forward, 1024x1024, S=320 prompt, "
-                                f"{T} new tokens, KV cache" if args.config == "c2" else "C1 tiny plumbing config"),
+        "vs_baseline": None, "dtype": "bf16" if mode == "perf" else "bf16 (LLM linear weights fp8 e4m3, weight-only)",
+        "data": "synthetic",
+        "config": {"workload": {"c2": "C2: LLaVA-7B + CLIP ViT-L/14 + SAM-H refer-seg forward, 1024x1024, S=320 prompt, "
+                                      f"{T} new tokens, KV cache",
+                                "c5": "C5: 13B LLM + CLIP ViT-L/14 + SAM-H refer-seg forward, fp8-weight LLM, 1024x1024, S=320 "
+                                      f"prompt, {T} new tokens, KV cache",
+                                "tiny": "C1 tiny plumbing config"}[args.config],
                    "batch_per_gpu": B, "global_batch": n_global, "parallelism": f"dp{world}",
                    "max_new_tokens": T, "weights": "random-init N(0,0.02^2) rounded to bf16"},
         "roofline": roofline,
