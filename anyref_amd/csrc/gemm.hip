@@ -552,6 +552,10 @@ static const GemmKnobs& knobs() {
   return k;
 }
 
+// make sure `s` owns a split-K workspace of at least `bytes` (call before capturing `s` into a graph:
+// growing the workspace synchronises the stream)
+void gemm_reserve_workspace(hipStream_t s, size_t bytes) { (void)splitk_workspace(s, bytes); }
+
 template <typename T>
 void launch_gemm(const GemmArgs& a_in, hipStream_t s) {
   GemmArgs a = a_in;

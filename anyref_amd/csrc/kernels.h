@@ -96,6 +96,7 @@ struct GemmArgs {
 };
 template <typename T>
 void launch_gemm(const GemmArgs& a, hipStream_t s);
+void gemm_reserve_workspace(hipStream_t s, size_t bytes);
 
 // Small-M weight-streaming GEMV for the decode step (HBM-bound):
 // y[b, n] = act(sum_k xn[b,k] W[n,k]) (+ resid) where xn = rmsnorm(x) * gain if gain != null.

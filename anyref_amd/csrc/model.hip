@@ -832,6 +832,8 @@ void Model<T>::decode_step_graph(hipStream_t s, int B, bool keep_q) {
   if (it == decode_graphs_.end()) {
     if (keep_q) ensure_q_last();
     if (!cap_stream_) HIP_TRY(hipStreamCreateWithFlags(&cap_stream_, hipStreamNonBlocking));
+    // the MFMA decode path (B > 4) uses split-K: its slab workspace must exist before the capture
+    gemm_reserve_workspace(cap_stream_, (size_t)8 * B * std::max(std::max(3 * cfg.llm_dim, 2 * cfg.llm_mlp), cfg.llm_vocab) * 4);
     hipGraph_t g = nullptr;
     hipGraphExec_t ge = nullptr;
     HIP_TRY(hipStreamBeginCapture(cap_stream_, hipStreamCaptureModeRelaxed));
@@ -967,14 +969,24 @@ void Model<T>::llm_decode_step(hipStream_t s, int B, bool keep_q) {
     da.pos = pos_dev_; da.rope = rope_tab_; da.q_keep = keep_q ? q_last_ : nullptr; da.sync = dec_sync_;
     layers_done = launch_decode_layers<T>(da, s);
   }
+  // More than 4 sequences per call: the FMA GEMV would stream every weight twice (4 batch rows per pass) and
+  // its VALU work grows with B, so the linears go through the MFMA GEMM (M = B rows of a 64/128-row tile,
+  // split-K to fill the chip: weights are read once) with the norms / SwiGLU as in prefill.
+  const bool mfma_decode = sizeof(T) == 2 && B > 4;
+  bool h_ready = false;
   for (int i = 0; i < nl && !layers_done; ++i) {
     LlmLayer& L = llm_layers_[i];
     T* kc = kcache_ + cache_layer_stride_ * i;
     T* vc = vcache_ + cache_layer_stride_ * i;
-    GemvArgs g;
-    g.x = d_x_; g.ldx = H; g.gain = L.in_norm.g; g.eps = c.llm_rms_eps; gemv_w(g, L.qkv); g.y = d_qkv_;
-    g.ldy = 3 * H; g.B = B; g.N = 3 * H; g.K = H;
-    launch_gemv<T>(g, s);
+    if (mfma_decode) {
+      if (!h_ready) norm(s, d_x_, H, L.in_norm, l_h_, H, B, H, c.llm_rms_eps, false, true);
+      gemm(s, l_h_, H, L.qkv, d_qkv_, 3 * H, B, ACT_NONE, true);
+    } else {
+      GemvArgs g;
+      g.x = d_x_; g.ldx = H; g.gain = L.in_norm.g; g.eps = c.llm_rms_eps; gemv_w(g, L.qkv); g.y = d_qkv_;
+      g.ldy = 3 * H; g.B = B; g.N = 3 * H; g.K = H;
+      launch_gemv<T>(g, s);
+    }
     T* qk = (keep_q && i == nl - 1) ? q_last_ : nullptr;
     if (!launch_decode_attn<T>(d_qkv_, B, nh, hd, pos_dev_, rope_tab_, kc, vc, S, 1.f / sqrtf((float)hd), d_att_, qk,
                                s)) {
@@ -988,6 +1000,16 @@ void Model<T>::llm_decode_step(hipStream_t s, int B, bool keep_q) {
       a.scale = 1.f / sqrtf((float)hd);
       a.kv_len = kvlen_dev_;
       launch_attention<T>(a, s);
+    }
+    if (mfma_decode) {
+      launch_convert<T>(d_att_, H, l_att_, H, B, H, s);
+      if (!gemm(s, l_att_, H, L.o, d_x_, H, B, ACT_NONE, true, d_x_, H, nullptr, &L.post_norm, l_h_))
+        norm(s, d_x_, H, L.post_norm, l_h_, H, B, H, c.llm_rms_eps, false, true);
+      gemm(s, l_h_, H, L.gu, l_gu_, 2 * F, B, ACT_NONE, false);
+      launch_swiglu<T>(l_gu_, B, F, l_act_, s);
+      h_ready = gemm(s, l_act_, F, L.down, d_x_, H, B, ACT_NONE, true, d_x_, H, nullptr,
+                     i + 1 < nl ? &llm_layers_[i + 1].in_norm : nullptr, l_h_);
+      continue;
     }
     GemvArgs o;
     o.x = d_att_; o.ldx = H; gemv_w(o, L.o); o.y = d_x_; o.resid = d_x_; o.ldy = H; o.B = B; o.N = H; o.K = H;

@@ -373,7 +373,7 @@ static float run_cold(K kern, int BM, int BN, size_t lds, GA a, const std::vecto
 }
 
 int main() {
-  const int shapes[][3] = {{320, 12288, 4096}, {320, 22016, 4096}, {4096, 3840, 1280}, {4096, 5120, 1280}, {4096, 1280, 5120}, {4900, 3840, 1280}, {257, 4096, 1024}};
+  const int shapes[][3] = {{320, 22016, 4096}, {320, 12288, 4096}, {320, 27648, 5120}};
   for (auto& sh : shapes) {
     const int M = sh[0], N = sh[1], K = sh[2];
     std::vector<uint16_t> hA((size_t)M * K), hW((size_t)N * K);
@@ -396,7 +396,7 @@ int main() {
     const float d_ = run_cold(v3<128, 128, 2, 4, 4>, 128, 128, 4 * 256 * 128, a1, Ws, it, 512);
     const float e_ = run_cold(v2<64, 256, 1, 4>, 64, 256, 2 * 320 * 128, a1, Ws, it, 256);
     const float f_ = run_cold(v3<64, 256, 1, 4, 3>, 64, 256, 3 * 320 * 128, a1, Ws, it, 256);
-    const float g_ = run_cold(v3<256, 256, 2, 4, 2>, 256, 256, 2 * 512 * 128, a1, Ws, it, 512);
+    const float g_ = run_cold(v3<64, 512, 1, 8, 2>, 64, 512, 2 * 576 * 128, a1, Ws, it, 512);
     // check: v3 NS=4 (last to write C1 among 128^2) vs v2: rerun both once
     a0.W = Ws[0]; a1.W = Ws[0];
     run_cold(v2<128, 128, 2, 4>, 128, 128, 2 * 256 * 128, a0, Ws, 1, 512);
@@ -407,7 +407,7 @@ int main() {
     run_cold(v3<64, 256, 1, 4, 3>, 64, 256, 3 * 320 * 128, a1, Ws, 1, 256);
     CK(hipMemcpy(h1.data(), C1, h1.size() * 2, hipMemcpyDeviceToHost));
     size_t bad2 = 0; for (size_t i = 0; i < h0.size(); ++i) bad2 += h0[i] != h1[i];
-    printf("M=%5d N=%6d K=%5d cold(%d W) | 128^2: v2 %6.1f  v3/2 %6.1f  v3/3 %6.1f  v3/4 %6.1f | 64x256: v2 %6.1f  v3/3 %6.1f | 256^2 v3/2 %6.1f | mismatch %zu %zu\n",
+    printf("M=%5d N=%6d K=%5d cold(%d W) | 128^2: v2 %6.1f  v3/2 %6.1f  v3/3 %6.1f  v3/4 %6.1f | 64x256: v2 %6.1f  v3/3 %6.1f | 64x512/8w v3/2 %6.1f | mismatch %zu %zu\n",
            M, N, K, nW, a_, b_, c_, d_, e_, f_, g_, bad, bad2);
     fflush(stdout);
     hipFree(A); hipFree(C0); hipFree(C1); for (auto w : Ws) hipFree(w);

@@ -219,3 +219,35 @@ def test_limits_and_error_paths():
     m.set_seg_token_idx(cfg.llm.vocab + 1)
     o2, masks2, _ = m.generate(*one, max_new_tokens=17)
     assert masks2 is None and torch.equal(o2, o)
+
+
+@pytest.mark.parametrize("mode", ["perf", "perf_fp8w"])
+def test_decode_mfma_path_batch_gt4(mode):
+    """More than 4 sequences per call take the MFMA-GEMM decode path (weights read once per step); every row
+    must still be what a batch of one produces: hidden states against the GEMV path (rows decoded one by one)
+    and against the oracle within the bf16 bound."""
+    from anyref_amd.model import AnyRefForCausalLM
+    from anyref_amd.quant import dequantized_state_dict
+    cfg = config_tiny()
+    sd = synth_state_dict(cfg, seed=21, scale=0.05)
+    B = 6
+    clip, sam, ids = make_inputs(cfg, B, seed=22, L=24)             # ragged prompts: 24, 21, ..., 9 tokens
+    ids_p, mask = pad(ids)
+    sizes, H, W = [(224, 224)] * B, [224] * B, [224] * B
+    m = AnyRefForCausalLM.from_state_dict(cfg, {k: v.cuda() for k, v in sd.items()}, mode=mode, max_batch=B, max_seg=4)
+    m.config.eos_token_id = None
+    (o6, _, _), ex6 = m.generate(clip, ids_p, sam, sizes, H, W, max_new_tokens=8, attention_masks=mask, _return_extras=True)
+    sd_ref = dequantized_state_dict(sd) if mode == "perf_fp8w" else sd
+    for b in range(B):
+        (o1, _, _), ex1 = m.generate(clip[b:b + 1], ids[b][None], sam[b:b + 1], sizes[:1], H[:1], W[:1], max_new_tokens=8,
+                                     _return_extras=True)
+        n = len(ids[b]) + cfg.clip.n_patches - 1 + 7
+        d = (ex6["hidden"][b, :n] - ex1["hidden"][0, :n]).abs().max().item()
+        assert d < 0.1, f"row {b}: batched (MFMA) vs single (GEMV) hidden differ by {d}"
+        if b < 2:
+            with torch.no_grad():
+                ref = O.anyref_generate(sd_ref, cfg, clip[b:b + 1], [ids[b]], sam[b:b + 1], sizes[:1], H[:1], W[:1],
+                                        max_new_tokens=8, eos=False)
+            if o6[b, : len(ids[b]) + 8].cpu().tolist() == ref["output_ids"][0].tolist():
+                herr = (ex6["hidden"][b, :n].cpu() - ref["hidden"][0][:n]).abs().max().item()
+                assert herr < 0.15, f"row {b}: hidden err vs oracle {herr}"
