@@ -140,7 +140,11 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int qi = lane & 15, g = lane >> 4;  // this lane's query (column) and lane group
-  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * BQ;
+  // kv_splits > 1 (few queries, many keys: the mask decoder's token -> image attention is 7 x 4096 on 8 heads =
+  // 8 workgroups walking 128 tiles each): blockIdx.x = q-block * splits + split, every split writes an
+  // un-normalised partial (O, m, l) and attn_combine_kernel merges them
+  const int split = (int)blockIdx.x % a.kv_splits;
+  const int b = blockIdx.z, h = blockIdx.y, q0 = ((int)blockIdx.x / a.kv_splits) * BQ;
   const int kv_len = a.kv_len ? a.kv_len[b] : a.Sk;
   const int q_len = a.q_len ? a.q_len[b] : a.Sq;
   if (q0 >= q_len) return;  // uniform per workgroup
@@ -245,8 +249,14 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
       if (v < BKV * VVEC) *reinterpret_cast<uint4v*>(&Vs[row * LDV + d]) = vreg[i];
     }
   };
-  if (kv_end > 0) gload_tile(0);
-  for (int kt = 0; kt < kv_end; kt += BKV) {
+  int kt_begin = 0;
+  if (a.kv_splits > 1) {
+    const int chunk = cdiv(cdiv(kv_end, a.kv_splits), BKV) * BKV;
+    kt_begin = split * chunk;
+    kv_end = kv_end < kt_begin + chunk ? kv_end : kt_begin + chunk;
+  }
+  if (kv_end > kt_begin) gload_tile(kt_begin);
+  for (int kt = kt_begin; kt < kv_end; kt += BKV) {
     sstore_tile();
     __syncthreads();
     if (kt + BKV < kv_end) gload_tile(kt + BKV);
@@ -392,6 +402,19 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
   // ---- normalise + store: lane (query qi, group g) holds O[query][d = 16*db + 4g + r] ------------
   l_run += __shfl_xor(l_run, 16, 64);
   l_run += __shfl_xor(l_run, 32, 64);
+  if (a.kv_splits > 1) {
+    if (q_ok) {
+      const int64_t row = (((int64_t)split * a.B + b) * a.H + h) * a.Sq + iq;
+      float* po = a.part_o + row * HD;
+#pragma unroll
+      for (int d = 0; d < DB; ++d) *reinterpret_cast<float4v*>(po + d * 16 + 4 * g) = ot[d];
+      if (g == 0) {
+        a.part_ml[row * 2] = m_run;
+        a.part_ml[row * 2 + 1] = l_run;
+      }
+    }
+    return;
+  }
   if (q_ok) {
     const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
     T* Ob = reinterpret_cast<T*>(a.O) + (int64_t)b * a.o_bs + (int64_t)h * a.o_hs + (int64_t)iq * a.o_rs;
@@ -414,8 +437,54 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
   }
 }
 
+// merge of the kv_splits partial results: out = sum_s w_s O_s / sum_s w_s l_s, w_s = exp(m_s - max m)
+// (exp2 when the partials are in the log2 domain: bf16 path)
+template <typename T>
+__global__ __launch_bounds__(256) void attn_combine_kernel(AttnArgs a, int HD) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t rows = (int64_t)a.B * a.H * a.Sq;
+  if (i >= rows * HD) return;
+  const int d = (int)(i % HD);
+  const int64_t row = i / HD;
+  const int iq = (int)(row % a.Sq), h = (int)((row / a.Sq) % a.H), b = (int)(row / ((int64_t)a.Sq * a.H));
+  float M = -INFINITY;
+  for (int s = 0; s < a.kv_splits; ++s) M = fmaxf(M, a.part_ml[(s * rows + row) * 2]);
+  float o = 0.f, l = 0.f;
+  for (int s = 0; s < a.kv_splits; ++s) {
+    const float m = a.part_ml[(s * rows + row) * 2];
+    const float w = m == -INFINITY ? 0.f : (sizeof(T) == 2 ? exp2f(m - M) : expf(m - M));
+    o = fmaf(w, a.part_o[(s * rows + row) * HD + d], o);
+    l = fmaf(w, a.part_ml[(s * rows + row) * 2 + 1], l);
+  }
+  const float v = l > 0.f ? o / l : 0.f;
+  const int64_t off = (int64_t)b * a.o_bs + (int64_t)h * a.o_hs + (int64_t)iq * a.o_rs + d;
+  if (a.o_f32) reinterpret_cast<float*>(a.O)[off] = v;
+  else reinterpret_cast<T*>(a.O)[off] = from_f32<T>(v);
+}
+
+// per-stream partial-result workspace (grown on demand, like the split-K slabs in gemm.hip)
+static float* attn_workspace(hipStream_t s, size_t bytes) {
+  struct Ws { hipStream_t s; float* p; size_t cap; };
+  static thread_local std::vector<Ws> pool;
+  for (auto& w : pool)
+    if (w.s == s) {
+      if (w.cap < bytes) {
+        HIP_TRY(hipStreamSynchronize(s));
+        (void)hipFree(w.p);
+        HIP_TRY(hipMalloc((void**)&w.p, bytes));
+        w.cap = bytes;
+      }
+      return w.p;
+    }
+  Ws w{s, nullptr, bytes};
+  HIP_TRY(hipMalloc((void**)&w.p, bytes));
+  pool.push_back(w);
+  return w.p;
+}
+
 template <typename T, int HD>
-static void attn_launch(const AttnArgs& a, hipStream_t s) {
+static void attn_launch(const AttnArgs& a_in, hipStream_t s) {
+  AttnArgs a = a_in;
   constexpr int KS = AMma<T>::KS, VEC = AMma<T>::VEC, BKV = AttnTile<T>::BKV;
   constexpr int HDK = (HD + KS - 1) / KS * KS, LDK = HDK + VEC;
   constexpr int LDV = sizeof(T) == 2 ? ((HD * 2 + 255) / 256 * 256 + 32) / 2 : HD + VEC;
@@ -428,12 +497,30 @@ static void attn_launch(const AttnArgs& a, hipStream_t s) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
-  dim3 grid(cdiv(a.Sq, 64), a.H, a.B);
+  // few query blocks over many keys: split the keys until ~256 workgroups (at least 256 keys per split)
+  a.kv_splits = 1;
+  const int64_t wgs = (int64_t)cdiv(a.Sq, 64) * a.H * a.B;
+  if (!a.causal && !a.kv_len && wgs < 128 && a.Sk >= 1024) {
+    int sp = (int)(256 / wgs);
+    sp = sp > a.Sk / 256 ? a.Sk / 256 : sp;
+    a.kv_splits = sp > 16 ? 16 : (sp < 1 ? 1 : sp);
+  }
+  if (a.kv_splits > 1) {
+    const size_t rows = (size_t)a.kv_splits * a.B * a.H * a.Sq;
+    float* ws = attn_workspace(s, rows * (HD + 2) * sizeof(float));
+    a.part_o = ws;
+    a.part_ml = ws + rows * HD;
+  }
+  dim3 grid(cdiv(a.Sq, 64) * a.kv_splits, a.H, a.B);
   static const std::string tag = std::string(sizeof(T) == 2 ? "attn_bf16_hd" : "attn_f32_hd") + std::to_string(HD);
   const double flops = 4.0 * a.B * a.H * (double)a.Sq * a.Sk * HD * (a.causal ? 0.5 : 1.0);
   const double bytes = (double)a.B * a.H * HD * sizeof(T) * (2.0 * a.Sq + 2.0 * a.Sk);
   ProfScope prof(tag.c_str(), flops, bytes, s);
   hipLaunchKernelGGL((attn_kernel<T, HD>), grid, dim3(256), lds, s, a);
+  if (a.kv_splits > 1) {
+    const int64_t n = (int64_t)a.B * a.H * a.Sq * HD;
+    hipLaunchKernelGGL((attn_combine_kernel<T>), dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s, a, HD);
+  }
 }
 
 template <typename T>

@@ -167,6 +167,10 @@ struct AttnArgs {
   int64_t rel_hs = 0;  // head stride of P (elements)
   int rel_ld = 0;      // row stride of P = 2*Np
   int o_f32 = 0;  // 1: O is f32 instead of T (decode step feeds the f32 GEMV)
+  // set by the launcher: keys split over kv_splits workgroups per query block, partials merged afterwards
+  int kv_splits = 1;
+  float* part_o = nullptr;   // [splits][B][H][Sq][hd] un-normalised O
+  float* part_ml = nullptr;  // [splits][B][H][Sq][2] running max, running sum
 };
 template <typename T>
 void launch_attention(const AttnArgs& a, hipStream_t s);

@@ -11,6 +11,7 @@ clip, sam, ids = make_inputs(cfg, 1, seed=1); clip, sam = clip.to(dev), sam.to(d
 m = AnyRefForCausalLM.from_state_dict(cfg, sd, mode='perf', max_batch=1, max_seg=2)
 emb = torch.randn(1, 320, 4096, device=dev) * 0.02
 which = sys.argv[1]
-f = {'sam': lambda: m.sam_encode(sam), 'prefill': lambda: m.llm_forward(emb), 'clip': lambda: m.encode_images(clip)}[which]
+e = m.sam_encode(sam)[0]; pp = torch.randn(1, 256, device=dev)
+f = {'mask': lambda: m.mask_decode(e, pp, (1024, 1024), (1024, 1024)), 'sam': lambda: m.sam_encode(sam), 'prefill': lambda: m.llm_forward(emb), 'clip': lambda: m.encode_images(clip)}[which]
 for _ in range(4): f()
 torch.cuda.synchronize()

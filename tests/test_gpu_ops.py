@@ -159,6 +159,8 @@ def ref_attention(q, k, v, scale, causal, kv_len, rel_h, rel_w, kw):
     (3, 8, 6, 6, 32, 0),          # token self attention
     (2, 2, 130, 130, 80, 1),      # hd 80, causal, ragged tail tiles
     (2, 2, 100, 130, 80, 0),      # hd 80, Sq != Sk
+    (1, 8, 7, 4096, 16, 0),       # SAM-H mask decoder token -> image: keys split over workgroups + merge
+    (1, 4, 70, 2500, 32, 0),      # two query blocks, ragged key splits
 ])
 def test_attention(lib, ty, B, H, Sq, Sk, hd, causal):
     g = torch.Generator().manual_seed(Sq * 3 + Sk + hd)
