@@ -115,13 +115,18 @@ __device__ inline void lds_tr_blocks<8>(uint32_t addr, uint2v (&f)[8]) {
 
 __device__ inline uint32_t pack_bf16x2(float lo, float hi) { return (uint32_t)f2bf(lo).x | ((uint32_t)f2bf(hi).x << 16); }
 
-template <typename T, int HD>
-__global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
+// NWV waves of 16 queries each (BQ = 16 NWV queries per workgroup) and BKV keys per tile.  Default 4 x 64;
+// 7 x 80 for the 14 x 14 SAM windows (196 tokens: 2 query blocks x 3 key tiles per window-head where 4 x 64
+// needs 4 x 4 with the last of each nearly empty): 80 -> 73 us per window layer.  Measured alternatives:
+// 5 x 80 87 us, 4 x 80 123 us, 8 x 80 75 us, 7 x 64 78 us, 8 x 64 80 us (register-limited occupancy decides).
+template <typename T, int HD, int NWV = 4, int BKV_ = 0>
+__global__ __launch_bounds__(NWV * 64) void attn_kernel(AttnArgs a) {
+  constexpr int NT = NWV * 64;
   using M_ = AMma<T>;
   constexpr int KS = M_::KS, VEC = M_::VEC;
   constexpr bool BF = sizeof(T) == 2;
-  constexpr int BKV = AttnTile<T>::BKV;
-  constexpr int BQ = 64;
+  constexpr int BKV = BKV_ > 0 ? BKV_ : AttnTile<T>::BKV;
+  constexpr int BQ = 16 * NWV;
   constexpr int HDK = (HD + KS - 1) / KS * KS;  // QK^T contraction length (zero padded)
   constexpr int LDK = HDK + VEC;                // K tile row stride
   // V tile row stride (row-major [key][d]).  bf16: the transposed reads (ds_read_b64_tr_b16) fetch, per
@@ -175,12 +180,12 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
   if (a.rel_p) {
     const float* P = a.rel_p + (int64_t)h * a.rel_hs + ((int64_t)b * a.Sq + q0) * a.rel_ld;
     const int np = a.rel_ld / 2;
-    for (int i = tid; i < BQ * a.kh; i += 256) {
+    for (int i = tid; i < BQ * a.kh; i += NT) {
       const int r = i / a.kh, c = i % a.kh;
       const int y = (q0 + r) / a.kw;
       relh_s[i] = q0 + r < q_len ? P[(int64_t)r * a.rel_ld + (y - c + a.kh - 1)] * bsc : 0.f;
     }
-    for (int i = tid; i < BQ * a.kw; i += 256) {
+    for (int i = tid; i < BQ * a.kw; i += NT) {
       const int r = i / a.kw, c = i % a.kw;
       const int x = (q0 + r) % a.kw;
       relw_s[i] = q0 + r < q_len ? P[(int64_t)r * a.rel_ld + np + (x - c + a.kw - 1)] * bsc : 0.f;
@@ -188,11 +193,11 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
   } else if (has_rel) {
     const float* rh = a.rel_h + ((int64_t)b * a.H + h) * a.Sq * a.kh;
     const float* rw = a.rel_w + ((int64_t)b * a.H + h) * a.Sq * a.kw;
-    for (int i = tid; i < BQ * a.kh; i += 256) {
+    for (int i = tid; i < BQ * a.kh; i += NT) {
       const int r = i / a.kh, c = i % a.kh;
       relh_s[i] = q0 + r < q_len ? rh[(int64_t)(q0 + r) * a.kh + c] * bsc : 0.f;
     }
-    for (int i = tid; i < BQ * a.kw; i += 256) {
+    for (int i = tid; i < BQ * a.kw; i += NT) {
       const int r = i / a.kw, c = i % a.kw;
       relw_s[i] = q0 + r < q_len ? rw[(int64_t)(q0 + r) * a.kw + c] * bsc : 0.f;
     }
@@ -221,18 +226,18 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
   // T14): staged synchronously, the waves spent 65 % of their cycles waiting on these loads (SQ_WAIT_ANY /
   // SQ_WAVE_CYCLES on the SAM global-attention launch).
   constexpr int KVEC = HDK / VEC, VVEC = HD / VEC;
-  constexpr int KPT = (BKV * KVEC + 255) / 256, VPT = (BKV * VVEC + 255) / 256;  // vectors per thread
+  constexpr int KPT = (BKV * KVEC + NT - 1) / NT, VPT = (BKV * VVEC + NT - 1) / NT;  // vectors per thread
   uint4v kreg[KPT], vreg[VPT];
   auto gload_tile = [&](int kt) {
 #pragma unroll
     for (int i = 0; i < KPT; ++i) {
-      const int v = tid + i * 256, row = v / KVEC, d = (v % KVEC) * VEC, j = kt + row;
+      const int v = tid + i * NT, row = v / KVEC, d = (v % KVEC) * VEC, j = kt + row;
       kreg[i] = (v < BKV * KVEC && j < kv_end && d < HD) ? *reinterpret_cast<const uint4v*>(Kb + (int64_t)j * a.k_rs + d)
                                                         : uint4v{0, 0, 0, 0};
     }
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
-      const int v = tid + i * 256, row = v / VVEC, d = (v % VVEC) * VEC, j = kt + row;
+      const int v = tid + i * NT, row = v / VVEC, d = (v % VVEC) * VEC, j = kt + row;
       vreg[i] = (v < BKV * VVEC && j < kv_end) ? *reinterpret_cast<const uint4v*>(Vb + (int64_t)j * a.v_rs + d)
                                                : uint4v{0, 0, 0, 0};
     }
@@ -240,12 +245,12 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
   auto sstore_tile = [&]() {
 #pragma unroll
     for (int i = 0; i < KPT; ++i) {
-      const int v = tid + i * 256, row = v / KVEC, d = (v % KVEC) * VEC;
+      const int v = tid + i * NT, row = v / KVEC, d = (v % KVEC) * VEC;
       if (v < BKV * KVEC) *reinterpret_cast<uint4v*>(&Ks[row * LDK + d]) = kreg[i];
     }
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
-      const int v = tid + i * 256, row = v / VVEC, d = (v % VVEC) * VEC;
+      const int v = tid + i * NT, row = v / VVEC, d = (v % VVEC) * VEC;
       if (v < BKV * VVEC) *reinterpret_cast<uint4v*>(&Vs[row * LDV + d]) = vreg[i];
     }
   };
@@ -482,24 +487,24 @@ static float* attn_workspace(hipStream_t s, size_t bytes) {
   return w.p;
 }
 
-template <typename T, int HD>
-static void attn_launch(const AttnArgs& a_in, hipStream_t s) {
+template <typename T, int HD, int NWV, int BKVP>
+static void attn_launch_cfg(const AttnArgs& a_in, hipStream_t s) {
   AttnArgs a = a_in;
-  constexpr int KS = AMma<T>::KS, VEC = AMma<T>::VEC, BKV = AttnTile<T>::BKV;
+  constexpr int KS = AMma<T>::KS, VEC = AMma<T>::VEC, BKV = BKVP > 0 ? BKVP : AttnTile<T>::BKV, BQ = 16 * NWV;
   constexpr int HDK = (HD + KS - 1) / KS * KS, LDK = HDK + VEC;
   constexpr int LDV = sizeof(T) == 2 ? ((HD * 2 + 255) / 256 * 256 + 32) / 2 : HD + VEC;
   size_t lds = sizeof(T) * (BKV * LDK + BKV * LDV);
-  if (a.rel_h || a.rel_p) lds += sizeof(float) * 64 * (a.kh + a.kw);
+  if (a.rel_h || a.rel_p) lds += sizeof(float) * BQ * (a.kh + a.kw);
   if (lds > 160 * 1024) throw std::runtime_error("attention: LDS budget exceeded");
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<T, HD>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<T, HD, NWV, BKVP>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
   // few query blocks over many keys: split the keys until ~256 workgroups (at least 256 keys per split)
   a.kv_splits = 1;
-  const int64_t wgs = (int64_t)cdiv(a.Sq, 64) * a.H * a.B;
+  const int64_t wgs = (int64_t)cdiv(a.Sq, BQ) * a.H * a.B;
   if (!a.causal && !a.kv_len && wgs < 128 && a.Sk >= 1024) {
     int sp = (int)(256 / wgs);
     sp = sp > a.Sk / 256 ? a.Sk / 256 : sp;
@@ -511,16 +516,29 @@ static void attn_launch(const AttnArgs& a_in, hipStream_t s) {
     a.part_o = ws;
     a.part_ml = ws + rows * HD;
   }
-  dim3 grid(cdiv(a.Sq, 64) * a.kv_splits, a.H, a.B);
-  static const std::string tag = std::string(sizeof(T) == 2 ? "attn_bf16_hd" : "attn_f32_hd") + std::to_string(HD);
+  dim3 grid(cdiv(a.Sq, BQ) * a.kv_splits, a.H, a.B);
+  static const std::string tag = std::string(sizeof(T) == 2 ? "attn_bf16_hd" : "attn_f32_hd") + std::to_string(HD) +
+                                 (NWV == 4 ? "" : "_w" + std::to_string(NWV));
   const double flops = 4.0 * a.B * a.H * (double)a.Sq * a.Sk * HD * (a.causal ? 0.5 : 1.0);
   const double bytes = (double)a.B * a.H * HD * sizeof(T) * (2.0 * a.Sq + 2.0 * a.Sk);
   ProfScope prof(tag.c_str(), flops, bytes, s);
-  hipLaunchKernelGGL((attn_kernel<T, HD>), grid, dim3(256), lds, s, a);
+  hipLaunchKernelGGL((attn_kernel<T, HD, NWV, BKVP>), grid, dim3(NWV * 64), lds, s, a);
   if (a.kv_splits > 1) {
     const int64_t n = (int64_t)a.B * a.H * a.Sq * HD;
     hipLaunchKernelGGL((attn_combine_kernel<T>), dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s, a, HD);
   }
+}
+
+template <typename T, int HD>
+static void attn_launch(const AttnArgs& a, hipStream_t s) {
+  // SAM windows (14 x 14 = 196 tokens, bf16, head dim 80): 7 waves x 80 keys tile the window 2 x 3
+  if constexpr (sizeof(T) == 2 && HD == 80) {
+    if (a.Sq == a.Sk && a.Sq > 192 && a.Sq <= 240 && !a.causal) {
+      attn_launch_cfg<T, HD, 7, 80>(a, s);
+      return;
+    }
+  }
+  attn_launch_cfg<T, HD, 4, 0>(a, s);
 }
 
 template <typename T>

@@ -1,10 +1,10 @@
 import ctypes as C, torch, sys, os
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from anyref_amd import _lib
 lib = _lib.load()
 P = lambda t: None if t is None else C.c_void_p(t.data_ptr())
 print('RB', os.environ.get('ANYREF_ATTN_RB'))
-for (B, H, S, hd, size, causal, name) in [(25, 16, 196, 80, 14, 0, 'sam window'), (1, 16, 4096, 80, 64, 0, 'sam global'),
+for (B, H, S, hd, size, causal, name) in [(25, 16, 196, 80, 14, 0, 'sam window'), (25, 16, 196, 80, 0, 0, 'window norel'), (25, 16, 192, 80, 0, 0, 'win192 norel'), (1, 16, 4096, 80, 64, 0, 'sam global'), (1, 16, 4096, 80, 0, 0, 'global norel'),
                                            (1, 16, 257, 64, 0, 0, 'clip'), (1, 32, 320, 128, 0, 1, 'llm prefill')]:
     q, k, v = (torch.randn(B, S, H, hd, device='cuda').bfloat16() for _ in range(3))
     o = torch.empty_like(q)
