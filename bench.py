@@ -25,7 +25,10 @@ import os
 import sys
 import time
 
-import torch
+# the host driver only supports dmabuf IPC: RCCL / cross-process device-memory sharing need this before HIP starts
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
