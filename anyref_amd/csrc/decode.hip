@@ -106,6 +106,7 @@ struct Phase {  // one weight-streaming phase: y[b, n] = act(sum_k W[n,k] * norm
   const float* resid;
   int N, K, ldx, ldy;
   float eps;
+  int ldw;  // row stride of W / W2 in elements (2K for the interleaved gate / up matrix)
 };
 
 template <typename T>
@@ -121,8 +122,8 @@ __device__ __forceinline__ void load_item(const Phase& p, int gw, int nwaves, in
   // gw is wave-uniform (readfirstlane), so both row bases live in SGPRs; the weight pointers come out
   // of a struct in memory, hence the explicit global address space (a flat load would also tick lgkmcnt)
   typedef const __attribute__((address_space(1))) uint4v* gptr;
-  const T* a0 = reinterpret_cast<const T*>(p.W) + (int64_t)r0 * p.K;
-  const T* a1 = reinterpret_cast<const T*>(dual ? p.W2 : p.W) + (int64_t)r1 * p.K;
+  const T* a0 = reinterpret_cast<const T*>(p.W) + (int64_t)r0 * p.ldw;
+  const T* a1 = reinterpret_cast<const T*>(dual ? p.W2 : p.W) + (int64_t)r1 * p.ldw;
 #pragma unroll
   for (int u = 0; u < DUNR; ++u) {
     const int k = c * CH + u * 64 * VN + lane * VN;
@@ -319,7 +320,7 @@ __global__ __launch_bounds__(DNT) void decode_layers_kernel(DecodeStepArgs a) {
   uint4v wcur[DUNR][DRW], wnxt[DUNR][DRW];
 
   auto qkv_phase = [&](const DecodeLayerPtrs& L) {
-    return Phase{L.qkv, nullptr, a.x, L.in_gain, a.qkv, nullptr, 3 * H, H, H, 3 * H, a.eps};
+    return Phase{L.qkv, nullptr, a.x, L.in_gain, a.qkv, nullptr, 3 * H, H, H, 3 * H, a.eps, H};
   };
   {
     const Phase p = qkv_phase(a.layers[0]);
@@ -349,7 +350,7 @@ __global__ __launch_bounds__(DNT) void decode_layers_kernel(DecodeStepArgs a) {
     grid_arrive(gs);
     // ---- x += W_o * att ----
     {
-      const Phase p{L.o, nullptr, a.att, nullptr, a.x, a.x, H, H, H, H, a.eps};
+      const Phase p{L.o, nullptr, a.att, nullptr, a.x, a.x, H, H, H, H, a.eps, H};
       prefetch_phase<T>(p, gw, nwaves, lane, wcur, wnxt);
       TR(4);
       if (!grid_wait(gs, &ok_lds)) return;
@@ -360,7 +361,7 @@ __global__ __launch_bounds__(DNT) void decode_layers_kernel(DecodeStepArgs a) {
     grid_arrive(gs);
     // ---- act = silu(W_gate * RMSNorm(x)) * (W_up * RMSNorm(x)) ----
     {
-      const Phase p{L.gate, L.up, a.x, L.post_gain, a.act, nullptr, F, H, H, F, a.eps};
+      const Phase p{L.gate, L.up, a.x, L.post_gain, a.act, nullptr, F, H, H, F, a.eps, L.gu_ld};
       prefetch_phase<T>(p, gw, nwaves, lane, wcur, wnxt);
       TR(7);
       if (!grid_wait(gs, &ok_lds)) return;
@@ -371,7 +372,7 @@ __global__ __launch_bounds__(DNT) void decode_layers_kernel(DecodeStepArgs a) {
     grid_arrive(gs);
     // ---- x += W_down * act ----
     {
-      const Phase p{L.down, nullptr, a.act, nullptr, a.x, a.x, H, F, F, H, a.eps};
+      const Phase p{L.down, nullptr, a.act, nullptr, a.x, a.x, H, F, F, H, a.eps, F};
       prefetch_phase<T>(p, gw, nwaves, lane, wcur, wnxt);
       TR(10);
       if (!grid_wait(gs, &ok_lds)) return;

@@ -73,6 +73,20 @@ __device__ __forceinline__ void epi_store4(const GemmArgs& a, const float* bias,
                                            int dm, int n, float4v v) {
   if constexpr (VEC) {  // N % 4 == 0: the four columns are all valid, rows are 16-byte aligned
     if (a.col_scale) v *= *reinterpret_cast<const float4v*>(a.col_scale + n);  // fp8 weights: per-row scale
+    if (a.swiglu_pairs) {  // columns (n, n+1), (n+2, n+3) are (gate, up) pairs -> output columns n/2, n/2 + 1
+      const float o0 = apply_act(v[0], ACT_SILU) * v[1], o1 = apply_act(v[2], ACT_SILU) * v[3];
+      const int64_t off = (int64_t)dm * a.ldc + (n >> 1);
+      if (a.c_f32) {
+        Cf[off] = o0;
+        Cf[off + 1] = o1;
+      } else if constexpr (sizeof(T) == 2) {
+        *reinterpret_cast<uint32_t*>(Ct + off) = (uint32_t)f2bf(o0).x | ((uint32_t)f2bf(o1).x << 16);
+      } else {
+        Ct[off] = from_f32<T>(o0);
+        Ct[off + 1] = from_f32<T>(o1);
+      }
+      return;
+    }
     if (bias) v += *reinterpret_cast<const float4v*>(bias + n);
     v = float4v{act_ct<ACT, sizeof(T) == 2>(v[0]), act_ct<ACT, sizeof(T) == 2>(v[1]), act_ct<ACT, sizeof(T) == 2>(v[2]), act_ct<ACT, sizeof(T) == 2>(v[3])};
     if (resid) v += *reinterpret_cast<const float4v*>(resid + (int64_t)dm * a.ldr + n);
@@ -86,6 +100,20 @@ __device__ __forceinline__ void epi_store4(const GemmArgs& a, const float* bias,
       *reinterpret_cast<float4v*>(Ct + (int64_t)dm * a.ldc + n) = v;
     }
   } else {  // scalar tail path (N not a multiple of 4 / unaligned)
+    if (a.swiglu_pairs) {
+#pragma unroll
+      for (int r = 0; r < 4; r += 2) {
+        if (n + r + 1 < a.N) {
+          float g = v[r], u = v[r + 1];
+          if (a.col_scale) { g *= a.col_scale[n + r]; u *= a.col_scale[n + r + 1]; }
+          const float o = apply_act(g, ACT_SILU) * u;
+          const int64_t off = (int64_t)dm * a.ldc + ((n + r) >> 1);
+          if (a.c_f32) Cf[off] = o;
+          else Ct[off] = from_f32<T>(o);
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       if (n + r < a.N) {
@@ -445,6 +473,13 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, int splits
     for (int z = 1; z < splits; ++z) acc += *reinterpret_cast<const float4v*>(slabs + z * slab_stride + e);
     acc *= a.alpha;
     if (a.col_scale) acc *= *reinterpret_cast<const float4v*>(a.col_scale + n);
+    if (a.swiglu_pairs) {
+      const float o0 = apply_act(acc[0], ACT_SILU) * acc[1], o1 = apply_act(acc[2], ACT_SILU) * acc[3];
+      const int64_t off = (int64_t)m * a.ldc + (n >> 1);
+      if (a.c_f32) { Cf[off] = o0; Cf[off + 1] = o1; }
+      else { Ct[off] = from_f32<T>(o0); Ct[off + 1] = from_f32<T>(o1); }
+      continue;
+    }
     if (a.bias) acc += *reinterpret_cast<const float4v*>(a.bias + n);
     acc = float4v{apply_act(acc[0], a.act), apply_act(acc[1], a.act), apply_act(acc[2], a.act), apply_act(acc[3], a.act)};
     if (a.resid) acc += *reinterpret_cast<const float4v*>(a.resid + (int64_t)m * a.ldr + n);
@@ -560,6 +595,8 @@ template <typename T>
 void launch_gemm(const GemmArgs& a_in, hipStream_t s) {
   GemmArgs a = a_in;
   if (a.norm_done) *a.norm_done = false;
+  if (a.swiglu_pairs && (a.N % 4 || a.bias || a.resid || a.row_map || a.act != ACT_NONE || a.batch != 1))
+    throw std::runtime_error("gemm: the SwiGLU epilogue takes interleaved gate/up rows, N % 4 == 0, and nothing else");
   constexpr int VEC = Mma<T>::VEC;
   // ---- split-K decision: few 64x64 tiles, deep K, plain row-major output ----
   if (!knobs().no_splitk && sizeof(T) == 2 && a.batch == 1 && !a.row_map && a.M <= 512 && a.K >= 2048 && a.N % 4 == 0 && a.ldc % 4 == 0 &&
@@ -577,9 +614,9 @@ void launch_gemm(const GemmArgs& a_in, hipStream_t s) {
       g.sA = g.K;   // column offset inside the same rows
       g.sW = g.K;
       g.C = ws; g.ldc = a.N; g.sC = slab; g.c_f32 = 1;
-      g.bias = nullptr; g.resid = nullptr; g.act = ACT_NONE; g.alpha = 1.f; g.col_scale = nullptr;
+      g.bias = nullptr; g.resid = nullptr; g.act = ACT_NONE; g.alpha = 1.f; g.col_scale = nullptr; g.swiglu_pairs = 0;
       launch_gemm<T>(g, s);
-      if (a.norm_out && a.norm_gain && a.N <= 8192 && a.norm_ld % 4 == 0) {
+      if (a.norm_out && a.norm_gain && a.N <= 8192 && a.norm_ld % 4 == 0 && !a.swiglu_pairs) {
         hipLaunchKernelGGL((splitk_reduce_norm_kernel<T>), dim3(a.M), dim3(256), 0, s, ws, splits, slab, a);
         if (a.norm_done) *a.norm_done = true;
         return;
@@ -625,6 +662,7 @@ void launch_gemm(const GemmArgs& a_in, hipStream_t s) {
                     (!a.resid || (a.ldr % 4 == 0 && a.sR % 4 == 0 && !((uintptr_t)a.resid & 15))) &&
                     (!a.bias || (a.sBias % 4 == 0 && !((uintptr_t)a.bias & 15)));
     a.vec_ok = al && (ov == 4 || ov == 2) ? 1 : 0;
+    if (a.swiglu_pairs) a.vec_ok = (a.N % 4 == 0 && a.ldc % 2 == 0 && !((uintptr_t)a.C & 3) && (!a.col_scale || !((uintptr_t)a.col_scale & 15))) ? 1 : 0;
   }
   const double flops = 2.0 * a.M * a.N * (double)a.K * a.batch;
   const double bytes = ((double)a.M * a.K + (double)a.N * a.K) * sizeof(T) * a.batch +
@@ -758,6 +796,7 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int b0, int nb) {
 
   const WT* __restrict__ W = reinterpret_cast<const WT*>(a.W);
   const WT* __restrict__ W2 = reinterpret_cast<const WT*>(a.W2);
+  const int ldw = a.ldw > 0 ? a.ldw : K;  // 2K: gate / up rows interleaved in one matrix
   const int nwaves = gridDim.x * 8;
   const int gw = blockIdx.x * 8 + wave;
   const int ngroups = cdiv(a.N, R);
@@ -777,11 +816,11 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int b0, int nb) {
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         const int n = n0 + r < a.N ? n0 + r : a.N - 1;
-        w[u][r] = k < K ? __builtin_nontemporal_load(reinterpret_cast<const uint4v*>(W + (int64_t)n * K + k))
+        w[u][r] = k < K ? __builtin_nontemporal_load(reinterpret_cast<const uint4v*>(W + (int64_t)n * ldw + k))
                         : uint4v{0, 0, 0, 0};
       }
       if (DUAL)
-        w[u][RW - 1] = k < K ? __builtin_nontemporal_load(reinterpret_cast<const uint4v*>(W2 + (int64_t)n0 * K + k))
+        w[u][RW - 1] = k < K ? __builtin_nontemporal_load(reinterpret_cast<const uint4v*>(W2 + (int64_t)n0 * ldw + k))
                              : uint4v{0, 0, 0, 0};
     }
   };
@@ -916,8 +955,8 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int b0, int nb) {
             float v = acc[r][b];
             float v2 = DUAL ? acc[RW - 1][b] : 0.f;
             if constexpr (W8) {
-              v *= a.wscale[n];
-              if (DUAL) v2 *= a.wscale2[n];
+              v *= a.wscale[(int64_t)n * a.ws_stride];
+              if (DUAL) v2 *= a.wscale2[(int64_t)n * a.ws_stride];
             }
             if (a.bias) v += a.bias[n];
             if (DUAL)

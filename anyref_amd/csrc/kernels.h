@@ -77,6 +77,9 @@ struct GemmArgs {
   int c_f32 = 0;  // 1: C is f32, 0: C is T
   float alpha = 1.f;
   int order = 3;   // bit 0: XCD-chunked block remap, bit 1: M-fastest tile order
+  // SwiGLU fused into the epilogue: W holds gate / up rows INTERLEAVED (row 2j = gate_j, 2j+1 = up_j), the
+  // output is [M, N/2]: C[m, j] = silu(c[m, 2j]) * c[m, 2j+1]  (no activation / residual / row map with it)
+  int swiglu_pairs = 0;
   // fp8 weight operand (bf16 LDS-DMA kernel only): W holds e4m3 bytes [N, K] (ldw, sW in bytes), the finished
   // column n is multiplied by col_scale[n]
   int w_fp8 = 0;
@@ -111,16 +114,19 @@ struct GemvArgs {
   const float* resid = nullptr;  // f32 [B,N] row stride ldy, may alias y
   int B = 1, N = 0, K = 0, ldx = 0, ldy = 0;
   int act = ACT_NONE;
-  // fp8 weight-only mode (T = bf16 activations): W / W2 are e4m3 bytes [N,K], y = (sum_k x q) * wscale[n]
+  int ldw = 0;  // row stride of W / W2 in elements (0: K); 2K for the interleaved gate/up matrix
+  // fp8 weight-only mode (T = bf16 activations): W / W2 are e4m3 bytes [N,K], y = (sum_k x q) * wscale[n * ws_stride]
   int w_fp8 = 0;
   const float* wscale = nullptr;
   const float* wscale2 = nullptr;
+  int ws_stride = 1;
 };
 template <typename T>
 void launch_gemv(const GemvArgs& a, hipStream_t s);
 // Row-wise fp8 (e4m3fn) weight quantisation: scale[n] = max|W[n,:]| / 448 (1 if the row is zero),
 // q[n,k] = RNE_e4m3(W[n,k] / scale[n]); src f32 [N, K] (row stride lds), q [N, K] bytes (row stride ldq)
-void launch_quant_fp8_rows(const float* src, int lds, int N, int K, uint8_t* q, int ldq, float* scale, hipStream_t s);
+void launch_quant_fp8_rows(const float* src, int lds, int N, int K, uint8_t* q, int ldq, float* scale, hipStream_t s,
+                           int scale_stride = 1);
 // q * scale -> bf16 [N, K] (prefill GEMM operand)
 void launch_dequant_fp8_rows(const uint8_t* q, int ldq, const float* scale, int N, int K, void* out_bf16, int ldo,
                              hipStream_t s);
@@ -287,11 +293,12 @@ struct DecodeLayerPtrs {
   const float* post_gain;  // post_attention_layernorm.weight
   const void* qkv;         // [3H, H] fused q,k,v
   const void* o;           // [H, H]
-  const void* gate;        // [F, H]
+  const void* gate;        // [F, H] rows at stride gu_ld (interleaved with up: gu_ld = 2H)
   const void* up;          // [F, H]
   const void* down;        // [H, F]
   void* kc;                // this layer's key cache   [B, maxS, nh, hd]
   void* vc;                // this layer's value cache
+  int gu_ld;               // row stride of gate / up in elements
 };
 struct DecodeStepArgs {
   const DecodeLayerPtrs* layers;  // device array [nl]

@@ -164,9 +164,10 @@ class Model : public ModelBase {
   // takes its split-K path; returns whether that happened (else the caller runs the norm itself)
   bool gemm(hipStream_t s, const T* A, int lda, const Lin<T>& l, void* C, int ldc, int M, int act, bool c_f32,
             const float* resid = nullptr, int ldr = 0, const int* row_map = nullptr, const Affine* nrm = nullptr,
-            T* nrm_out = nullptr) {
+            T* nrm_out = nullptr, bool swiglu = false) {
     GemmArgs a;
     bool fused = false;
+    a.swiglu_pairs = swiglu ? 1 : 0;
     if (nrm && nrm_out) {
       a.norm_gain = nrm->g; a.norm_out = nrm_out; a.norm_ld = l.n; a.norm_eps = cfg.llm_rms_eps; a.norm_done = &fused;
     }
@@ -204,11 +205,12 @@ class Model : public ModelBase {
   bool fp8w_ = false;
   T* deq_buf_ = nullptr;  // bf16 image of the largest fp8 weight (prefill operand)
   // pack rows of a raw f32 tensor as fp8 + scales into l (rows [row0, row0 + rows))
-  void pack_rows_fp8(Lin<T>& l, int row0, const std::string& name, int rows, int cols) {
+  // rstride 2: every second row of l (gate / up interleave), starting at row0
+  void pack_rows_fp8(Lin<T>& l, int row0, const std::string& name, int rows, int cols, int rstride = 1) {
     const RawTensor& t = raw(name);
     if (t.numel() != (int64_t)rows * cols || cols != l.k)
       throw std::runtime_error("shape mismatch for " + name + " (fp8 pack)");
-    launch_quant_fp8_rows(t.p, cols, rows, cols, l.w8 + (size_t)row0 * l.k, l.k, l.ws + row0, 0);
+    launch_quant_fp8_rows(t.p, cols, rows, cols, l.w8 + (size_t)row0 * l.k, l.k * rstride, l.ws + row0, 0, rstride);
   }
   Lin<T> alloc_fp8(int n, int k) {
     if (k % 16) throw std::runtime_error("fp8 weights need K % 16 == 0");
@@ -289,7 +291,7 @@ class Model : public ModelBase {
   T *kcache_ = nullptr, *vcache_ = nullptr, *q_last_ = nullptr;
   size_t cache_layer_stride_ = 0;
   float *l_x_ = nullptr, *hidden_all_ = nullptr, *l_logits_ = nullptr, *l_xlast_ = nullptr;
-  T *l_h_ = nullptr, *l_qkv_ = nullptr, *l_q_ = nullptr, *l_att_ = nullptr, *l_gu_ = nullptr, *l_act_ = nullptr;
+  T *l_h_ = nullptr, *l_qkv_ = nullptr, *l_q_ = nullptr, *l_att_ = nullptr, *l_act_ = nullptr;
   float *d_x_ = nullptr, *d_qkv_ = nullptr, *d_att_ = nullptr, *d_act_ = nullptr;
   DecodeLayerPtrs* llm_dec_ptrs_ = nullptr;  // device array for the persistent decode kernel
   unsigned* dec_sync_ = nullptr;
@@ -484,9 +486,9 @@ void Model<T>::finalize() {
         for (int j = 0; j < 3; ++j) pack_rows_fp8(L.qkv, j * H, lp + "self_attn." + names[j] + ".weight", H, H);
         L.o = alloc_fp8(H, H);
         pack_rows_fp8(L.o, 0, lp + "self_attn.o_proj.weight", H, H);
-        L.gu = alloc_fp8(2 * F, H);
-        pack_rows_fp8(L.gu, 0, lp + "mlp.gate_proj.weight", F, H);
-        pack_rows_fp8(L.gu, F, lp + "mlp.up_proj.weight", F, H);
+        L.gu = alloc_fp8(2 * F, H);  // rows interleaved: 2j = gate_j, 2j + 1 = up_j (SwiGLU in the GEMM epilogue)
+        pack_rows_fp8(L.gu, 0, lp + "mlp.gate_proj.weight", F, H, 2);
+        pack_rows_fp8(L.gu, 1, lp + "mlp.up_proj.weight", F, H, 2);
         L.down = alloc_fp8(H, F);
         pack_rows_fp8(L.down, 0, lp + "mlp.down_proj.weight", H, F);
       } else {
@@ -497,11 +499,11 @@ void Model<T>::finalize() {
         L.o = pack_linear(lp + "self_attn.o_proj.weight", "", H, H);
         L.gu.n = 2 * F;
         L.gu.k = H;
-        L.gu.w = talloc<T>((size_t)2 * F * H);
-        pack_rows(L.gu.w, 0, lp + "mlp.gate_proj.weight", F, H, H);
-        pack_rows(L.gu.w, F, lp + "mlp.up_proj.weight", F, H, H);
+        L.gu.w = talloc<T>((size_t)2 * F * H);  // rows interleaved: 2j = gate_j, 2j + 1 = up_j
+        pack_rows(L.gu.w, 0, lp + "mlp.gate_proj.weight", F, H, 2 * H);
+        pack_rows(L.gu.w + H, 0, lp + "mlp.up_proj.weight", F, H, 2 * H);
         L.gate_w = L.gu.w;
-        L.up_w = L.gu.w + (size_t)F * H;
+        L.up_w = L.gu.w + H;
         L.down = pack_linear(lp + "mlp.down_proj.weight", "", H, F);
         if (L.down.k != F) throw std::runtime_error("llm_mlp must be a multiple of 8");
       }
@@ -546,7 +548,6 @@ void Model<T>::finalize() {
     l_qkv_ = talloc<T>(R * 3 * H);
     l_q_ = talloc<T>(R * H);
     l_att_ = talloc<T>(R * H);
-    l_gu_ = talloc<T>(R * 2 * F);
     l_act_ = talloc<T>(R * F);
     l_logits_ = talloc<float>((size_t)MB * V);
     l_xlast_ = talloc<float>((size_t)MB * H);
@@ -562,7 +563,7 @@ void Model<T>::finalize() {
       for (int i = 0; i < nl; ++i) {
         LlmLayer& L = llm_layers_[i];
         hp[i] = DecodeLayerPtrs{L.in_norm.g, L.post_norm.g, L.qkv.w, L.o.w, L.gate_w, L.up_w, L.down.w,
-                                kcache_ + cache_layer_stride_ * i, vcache_ + cache_layer_stride_ * i};
+                                kcache_ + cache_layer_stride_ * i, vcache_ + cache_layer_stride_ * i, 2 * H};
       }
       llm_dec_ptrs_ = reinterpret_cast<DecodeLayerPtrs*>(dalloc(sizeof(DecodeLayerPtrs) * nl));
       HIP_TRY(hipMemcpy(llm_dec_ptrs_, hp.data(), sizeof(DecodeLayerPtrs) * nl, hipMemcpyHostToDevice));
@@ -943,8 +944,7 @@ void Model<T>::llm_prefill(hipStream_t s, int B, int Sp, const int* lens_dev, bo
     launch_attention<T>(a, s);
     if (!gemm(s, l_att_, H, L.o, l_x_, H, R, ACT_NONE, true, l_x_, H, nullptr, &L.post_norm, l_h_))
       norm(s, l_x_, H, L.post_norm, l_h_, H, R, H, c.llm_rms_eps, false, true);
-    gemm(s, l_h_, H, L.gu, l_gu_, 2 * F, R, ACT_NONE, false);
-    launch_swiglu<T>(l_gu_, R, F, l_act_, s);
+    gemm(s, l_h_, H, L.gu, l_act_, F, R, ACT_NONE, false, nullptr, 0, nullptr, nullptr, nullptr, true);  // silu(g) * u
     h_ready = gemm(s, l_act_, F, L.down, l_x_, H, R, ACT_NONE, true, l_x_, H, nullptr,
                    i + 1 < nl ? &llm_layers_[i + 1].in_norm : nullptr, l_h_);
   }
@@ -1005,8 +1005,7 @@ void Model<T>::llm_decode_step(hipStream_t s, int B, bool keep_q) {
       launch_convert<T>(d_att_, H, l_att_, H, B, H, s);
       if (!gemm(s, l_att_, H, L.o, d_x_, H, B, ACT_NONE, true, d_x_, H, nullptr, &L.post_norm, l_h_))
         norm(s, d_x_, H, L.post_norm, l_h_, H, B, H, c.llm_rms_eps, false, true);
-      gemm(s, l_h_, H, L.gu, l_gu_, 2 * F, B, ACT_NONE, false);
-      launch_swiglu<T>(l_gu_, B, F, l_act_, s);
+      gemm(s, l_h_, H, L.gu, l_act_, F, B, ACT_NONE, false, nullptr, 0, nullptr, nullptr, nullptr, true);
       h_ready = gemm(s, l_act_, F, L.down, d_x_, H, B, ACT_NONE, true, d_x_, H, nullptr,
                      i + 1 < nl ? &llm_layers_[i + 1].in_norm : nullptr, l_h_);
       continue;
@@ -1015,7 +1014,7 @@ void Model<T>::llm_decode_step(hipStream_t s, int B, bool keep_q) {
     o.x = d_att_; o.ldx = H; gemv_w(o, L.o); o.y = d_x_; o.resid = d_x_; o.ldy = H; o.B = B; o.N = H; o.K = H;
     launch_gemv<T>(o, s);
     GemvArgs m;
-    m.x = d_x_; m.ldx = H; m.gain = L.post_norm.g; m.eps = c.llm_rms_eps; gemv_w(m, L.gu, 0); gemv_w2(m, L.gu, F);
+    m.x = d_x_; m.ldx = H; m.gain = L.post_norm.g; m.eps = c.llm_rms_eps; gemv_w(m, L.gu, 0); gemv_w2(m, L.gu, 1); m.ldw = 2 * H; m.ws_stride = 2;
     m.y = d_act_; m.ldy = F; m.B = B; m.N = F; m.K = H;
     launch_gemv<T>(m, s);
     GemvArgs d;

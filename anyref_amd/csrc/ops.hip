@@ -956,7 +956,7 @@ template void launch_fill_rows_bias<bf16>(void*, int, const int*, int, const flo
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void quant_fp8_rows_kernel(const float* __restrict__ src, int lds, int K,
                                                              uint8_t* __restrict__ q, int ldq,
-                                                             float* __restrict__ scale) {
+                                                             float* __restrict__ scale, int sstride) {
   const int n = blockIdx.x, tid = threadIdx.x;
   const float* row = src + (int64_t)n * lds;
   float amax = 0.f;
@@ -967,7 +967,7 @@ __global__ __launch_bounds__(256) void quant_fp8_rows_kernel(const float* __rest
   __syncthreads();
   amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
   const float sc = amax > 0.f ? amax / FP8_E4M3_MAX : 1.f;
-  if (tid == 0) scale[n] = sc;
+  if (tid == 0) scale[(int64_t)n * sstride] = sc;
   uint8_t* out = q + (int64_t)n * ldq;
   for (int k = tid * 2; k < K; k += 512) {  // two values per v_cvt_pk_fp8_f32 (RNE, saturating)
     const float a = row[k] / sc, b = k + 1 < K ? row[k + 1] / sc : 0.f;
@@ -976,9 +976,10 @@ __global__ __launch_bounds__(256) void quant_fp8_rows_kernel(const float* __rest
     if (k + 1 < K) out[k + 1] = (uint8_t)((w >> 8) & 255);
   }
 }
-void launch_quant_fp8_rows(const float* src, int lds, int N, int K, uint8_t* q, int ldq, float* scale, hipStream_t s) {
+void launch_quant_fp8_rows(const float* src, int lds, int N, int K, uint8_t* q, int ldq, float* scale, hipStream_t s,
+                           int scale_stride) {
   if (N <= 0) return;
-  hipLaunchKernelGGL(quant_fp8_rows_kernel, dim3(N), dim3(256), 0, s, src, lds, K, q, ldq, scale);
+  hipLaunchKernelGGL(quant_fp8_rows_kernel, dim3(N), dim3(256), 0, s, src, lds, K, q, ldq, scale, scale_stride);
 }
 
 __global__ __launch_bounds__(256) void dequant_fp8_rows_kernel(const uint8_t* __restrict__ q, int ldq,
