@@ -320,7 +320,7 @@ __global__ __launch_bounds__(DNT) void decode_layers_kernel(DecodeStepArgs a) {
   uint4v wcur[DUNR][DRW], wnxt[DUNR][DRW];
 
   auto qkv_phase = [&](const DecodeLayerPtrs& L) {
-    return Phase{L.qkv, nullptr, a.x, L.in_gain, a.qkv, nullptr, 3 * H, H, H, 3 * H, a.eps, H};
+    return Phase{L.qkv, nullptr, a.x, L.in_gain, a.qkv, nullptr, 3 * H, H, H, 3 * H, a.eps, L.qkv_ld};
   };
   {
     const Phase p = qkv_phase(a.layers[0]);
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(DNT) void decode_layers_kernel(DecodeStepArgs a) {
     grid_arrive(gs);
     // ---- x += W_o * att ----
     {
-      const Phase p{L.o, nullptr, a.att, nullptr, a.x, a.x, H, H, H, H, a.eps, H};
+      const Phase p{L.o, nullptr, a.att, nullptr, a.x, a.x, H, H, H, H, a.eps, L.o_ld};
       prefetch_phase<T>(p, gw, nwaves, lane, wcur, wnxt);
       TR(4);
       if (!grid_wait(gs, &ok_lds)) return;
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(DNT) void decode_layers_kernel(DecodeStepArgs a) {
     grid_arrive(gs);
     // ---- x += W_down * act ----
     {
-      const Phase p{L.down, nullptr, a.act, nullptr, a.x, a.x, H, F, F, H, a.eps, F};
+      const Phase p{L.down, nullptr, a.act, nullptr, a.x, a.x, H, F, F, H, a.eps, L.down_ld};
       prefetch_phase<T>(p, gw, nwaves, lane, wcur, wnxt);
       TR(10);
       if (!grid_wait(gs, &ok_lds)) return;

@@ -299,6 +299,7 @@ struct DecodeLayerPtrs {
   void* kc;                // this layer's key cache   [B, maxS, nh, hd]
   void* vc;                // this layer's value cache
   int gu_ld;               // row stride of gate / up in elements
+  int qkv_ld, o_ld, down_ld;  // row strides of the other matrices (rows are padded, see model.hip Lin::ld)
 };
 struct DecodeStepArgs {
   const DecodeLayerPtrs* layers;  // device array [nl]

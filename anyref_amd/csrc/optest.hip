@@ -42,6 +42,7 @@ int anyref_op_gemv(int t, void* stream, const float* x, const float* gain, float
     GemvArgs a;
     a.x = x; a.ldx = K; a.gain = gain; a.eps = eps; a.W = W; a.W2 = W2; a.bias = bias; a.y = y; a.resid = resid;
     a.ldy = N; a.B = B; a.N = N; a.K = K; a.act = act;
+    if (const char* e = getenv("ANYREF_OPTEST_LDW_PAD")) a.ldw = K + atoi(e);  // probe: padded weight rows
     if (t == 0) launch_gemv<float>(a, (hipStream_t)stream); else launch_gemv<bf16>(a, (hipStream_t)stream);
   });
 }
