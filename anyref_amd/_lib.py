@@ -76,6 +76,7 @@ SYMBOLS = {
     "anyref_op_quant_fp8": (_I, [_P, _P, _I, _I, _P, _P]),
     "anyref_op_gemv_fp8": (_I, [_P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _I, _I, _I]),
     "anyref_op_iou_counts": (_I, [_P, _P, _P, _I, _L, _P]),
+    "anyref_op_avs_counts": (_I, [_P, _P, _P, _I, _L, _P, _I, _F, _P, _P]),
     "anyref_op_sam_preprocess": (_I, [_P, _P, _I, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_float), _P]),
     "anyref_op_gemv": (_I, [_I, _P, _P, _P, _F, _P, _P, _P, _P, _P, _I, _I, _I, _I]),
     "anyref_op_norm": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _F, _I]),

@@ -274,6 +274,8 @@ template <typename T>
 void launch_fill_rows_bias(void* dst, int ld, const int* rows, int nrows, const float* bias, int N, hipStream_t s);
 // SURVEY.md §8 f-2 / f-1 (the steps right after / before the path)
 void launch_iou_counts(const float* logits, const uint8_t* target, int n, int64_t hw, int64_t* counts, hipStream_t s);
+void launch_avs_counts(const float* logits, const uint8_t* target, int n, int64_t hw, const float* cuts, int nth,
+                       float cut_pred, int64_t* conf, int64_t* hist, hipStream_t s);
 void launch_sam_preprocess(const uint8_t* img, int h, int w, int S, const float* mean, const float* std_, float* out,
                            hipStream_t s);
 // per-row broadcast add: out[m,:] = a[m,:] + v[:]  (f32)

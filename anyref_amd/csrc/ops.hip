@@ -910,6 +910,79 @@ void launch_iou_counts(const float* logits, const uint8_t* target, int n, int64_
                      reinterpret_cast<unsigned long long*>(counts));
 }
 
+// f-2 (AVS): the per-pixel part of `mask_iou` and `Eval_Fmeasure` / `_eval_pr` (utils/pyutils.py:163-236) in one
+// pass over the logits.  The reference thresholds sigmoid(x) at 0.5 (strictly) and at pr_num = 255 values of
+// linspace(0, 1 - 1e-10); sigmoid is monotone, so every test `sigmoid(x) >= th_i` is `x >= cut_i` with
+// cut_i = the smallest f32 whose f32 sigmoid reaches th_i.  The host finds the cuts by bisection against the same
+// sigmoid the reference calls (anyref_amd/evalops.py), so the counts are exact, not "close".
+//   conf[m]    = {n00, n01, n10, n11}  (index 2 * pred + gt, pred = x >= cut_pred, gt in {0, 1})
+//   hist[m][b][g], b = #{i : x >= cut_i} in [0, nth]: pixels of label g whose sigmoid passes exactly the first b
+//   thresholds; tp_i = sum_{b > i} hist[m][b][1], #{y_temp}_i = sum_{b > i} (hist[m][b][0] + hist[m][b][1]).
+constexpr int AVS_MAX_TH = 255;
+__global__ __launch_bounds__(256) void avs_counts_kernel(const float* __restrict__ logits,
+                                                         const uint8_t* __restrict__ target, int64_t hw,
+                                                         const float* __restrict__ cuts, int nth, float cut_pred,
+                                                         unsigned long long* __restrict__ conf,
+                                                         unsigned long long* __restrict__ hist) {
+  __shared__ float cut_s[AVS_MAX_TH + 1];
+  __shared__ unsigned h_s[(AVS_MAX_TH + 1) * 2];
+  __shared__ unsigned c_s[4];
+  const int m = blockIdx.y;
+  for (int i = threadIdx.x; i <= AVS_MAX_TH; i += 256) cut_s[i] = i < nth ? cuts[i] : INFINITY;
+  for (int i = threadIdx.x; i < (AVS_MAX_TH + 1) * 2; i += 256) h_s[i] = 0;
+  if (threadIdx.x < 4) c_s[threadIdx.x] = 0;
+  __syncthreads();
+  const float* x = logits + (int64_t)m * hw;
+  const uint8_t* t = target + (int64_t)m * hw;
+  unsigned c[4] = {0, 0, 0, 0};
+  auto take = [&](float v, unsigned g) {
+    g = g ? 1u : 0u;
+    c[(v >= cut_pred ? 2u : 0u) + g] += 1;
+    // upper bound over the ascending cuts: b = #{i < nth : cut_i <= v} (NaN compares false everywhere -> 0,
+    // as (NaN >= th) is False in the reference); cut_s is +inf from nth on, 256 entries -> 8 steps
+    int b = 0;
+#pragma unroll
+    for (int step = (AVS_MAX_TH + 1) / 2; step > 0; step >>= 1)
+      if (v >= cut_s[b + step - 1]) b += step;
+    atomicAdd(&h_s[b * 2 + g], 1u);
+  };
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if ((hw & 3) == 0 && (((uintptr_t)x | (uintptr_t)t) & 15) == 0) {
+    for (int64_t i = i0; i < hw / 4; i += stride) {
+      const float4 v = reinterpret_cast<const float4*>(x)[i];
+      const uint32_t g = reinterpret_cast<const uint32_t*>(t)[i];
+      take(v.x, g & 255u); take(v.y, (g >> 8) & 255u); take(v.z, (g >> 16) & 255u); take(v.w, g >> 24);
+    }
+  } else {
+    for (int64_t i = i0; i < hw; i += stride) take(x[i], t[i]);
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    unsigned v = c[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(&c_s[k], v);
+  }
+  __syncthreads();
+  // integer atomics: the totals do not depend on the order of arrival
+  if (threadIdx.x < 4 && c_s[threadIdx.x]) atomicAdd(&conf[(int64_t)m * 4 + threadIdx.x], (unsigned long long)c_s[threadIdx.x]);
+  for (int i = threadIdx.x; i < (nth + 1) * 2; i += 256)
+    if (h_s[i]) atomicAdd(&hist[(int64_t)m * (nth + 1) * 2 + i], (unsigned long long)h_s[i]);
+}
+void launch_avs_counts(const float* logits, const uint8_t* target, int n, int64_t hw, const float* cuts, int nth,
+                       float cut_pred, int64_t* conf, int64_t* hist, hipStream_t s) {
+  if (nth < 1 || nth > AVS_MAX_TH) throw std::runtime_error("avs_counts: 1 <= number of thresholds <= 255");
+  if (n <= 0) return;
+  HIP_TRY(hipMemsetAsync(conf, 0, (size_t)n * 4 * sizeof(int64_t), s));
+  HIP_TRY(hipMemsetAsync(hist, 0, (size_t)n * (nth + 1) * 2 * sizeof(int64_t), s));
+  if (hw <= 0) return;
+  int64_t blocks = cdiv64(hw, 256 * 32);
+  blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
+  hipLaunchKernelGGL(avs_counts_kernel, dim3((unsigned)blocks, n), dim3(256), 0, s, logits, target, hw, cuts, nth,
+                     cut_pred, reinterpret_cast<unsigned long long*>(conf), reinterpret_cast<unsigned long long*>(hist));
+}
+
 // f-1: `sam_preprocess` (utils/refer_seg.py:560-570) on the resized uint8 HWC image: (x - mean) / std per
 // channel in f32 (IEEE division, bit-identical to the torch expression), CHW output zero-padded to S x S.
 __global__ __launch_bounds__(256) void sam_preprocess_kernel(const uint8_t* __restrict__ img, int h, int w, int S,

@@ -118,6 +118,11 @@ int anyref_op_iou_counts(void* stream, const float* logits, const uint8_t* targe
   OP_GUARD(launch_iou_counts(logits, target, n, hw, counts, (hipStream_t)stream));
 }
 
+int anyref_op_avs_counts(void* stream, const float* logits, const uint8_t* target, int n, int64_t hw,
+                         const float* cuts, int nth, float cut_pred, int64_t* conf, int64_t* hist) {
+  OP_GUARD(launch_avs_counts(logits, target, n, hw, cuts, nth, cut_pred, conf, hist, (hipStream_t)stream));
+}
+
 int anyref_op_sam_preprocess(void* stream, const uint8_t* img, int h, int w, int S, const float* mean3,
                              const float* std3, float* out) {
   OP_GUARD(launch_sam_preprocess(img, h, w, S, mean3, std3, out, (hipStream_t)stream));

@@ -43,6 +43,13 @@ int anyref_op_gemv_fp8(void* stream, const float* x, const float* gain, float ep
  * (device) = {I0, I1, O0, O1, T0, T1}; area_intersection = I, area_union = O + T - I, area_target = T. */
 int anyref_op_iou_counts(void* stream, const float* logits, const uint8_t* target, int n, int64_t hw,
                          int64_t* counts);
+/* SURVEY.md §8 f-2 (AVS), the per-pixel part of `mask_iou` and `Eval_Fmeasure` / `_eval_pr`
+ * (utils/pyutils.py:163-236; caller eval_avs_object.py:168-178) in one pass: logits f32 [n, hw], target u8
+ * [n, hw] (0 / non-zero), cuts f32 [nth] ascending (device; cut_i = smallest logit whose sigmoid reaches the
+ * i-th P/R threshold), cut_pred = smallest logit with sigmoid > 0.5.  conf i64 [n, 4] = counts by 2 * pred + gt;
+ * hist i64 [n, nth + 1, 2] = pixels by (number of thresholds passed, gt). nth <= 255. */
+int anyref_op_avs_counts(void* stream, const float* logits, const uint8_t* target, int n, int64_t hw,
+                         const float* cuts, int nth, float cut_pred, int64_t* conf, int64_t* hist);
 /* SURVEY.md §8 f-1, replaces `sam_preprocess` (utils/refer_seg.py:560-570) after ResizeLongestSide: img u8
  * HWC [h, w, 3] (device) -> out f32 CHW [3, S, S] (device), (x - mean3[c]) / std3[c], zero padded; mean3 /
  * std3 are HOST pointers. */

@@ -616,3 +616,49 @@ def sam_preprocess(image_hwc_u8: torch.Tensor, sam_image_size: int = 1024,
     x = (x - torch.tensor(pixel_mean).view(-1, 1, 1)) / torch.tensor(pixel_std).view(-1, 1, 1)
     h, w = x.shape[-2:]
     return F.pad(x, (0, sam_image_size - w, 0, sam_image_size - h))
+
+
+def avs_mask_iou(pred_logits: torch.Tensor, target: torch.Tensor, eps: float = 1e-7) -> torch.Tensor:
+    """utils/pyutils.py:163-190 mask_iou (size_average form; caller eval_avs_object.py:168): per mask,
+    |P & G| / |P | G| with P = sigmoid > 0.5; a mask whose ground truth is empty scores the fraction of
+    pixels it (correctly) leaves empty; mean over the N masks."""
+    assert pred_logits.dim() == 3 and pred_logits.shape == target.shape
+    n, npix = pred_logits.shape[0], pred_logits.shape[-1] * pred_logits.shape[-2]
+    empty_gt = target.sum(2).sum(1) == 0
+    p = (torch.sigmoid(pred_logits) > 0.5).int()
+    inter = (p * target).sum(2).sum(1)
+    union = torch.max(p, target).sum(2).sum(1)
+    both_empty = ((1 - target) * (1 - p)).sum(2).sum(1)
+    inter[empty_gt] = both_empty[empty_gt]
+    union[empty_gt] = npix
+    return torch.sum(inter / (union + eps)) / n
+
+
+def avs_pr_curve(prob: torch.Tensor, gt: torch.Tensor, num: int):
+    """utils/pyutils.py:223-236 _eval_pr on CPU tensors: precision / recall at `num` thresholds."""
+    prec, recall = torch.zeros(num), torch.zeros(num)
+    th = torch.linspace(0, 1 - 1e-10, num)
+    for i in range(num):
+        passed = (prob >= th[i]).float()
+        tp = (passed * gt).sum()
+        prec[i], recall[i] = tp / (passed.sum() + 1e-20), tp / (gt.sum() + 1e-20)
+    return prec, recall
+
+
+def avs_fmeasure(pred_logits: torch.Tensor, gt: torch.Tensor, pr_num: int = 255) -> float:
+    """utils/pyutils.py:193-220 Eval_Fmeasure without its (empty) log file: max over thresholds of the
+    F_beta curve (beta^2 = 0.3) averaged over the masks whose ground truth is not empty."""
+    prob = torch.sigmoid(pred_logits)
+    beta2 = 0.3
+    total, used = 0.0, 0
+    score = torch.zeros(pr_num)
+    for i in range(prob.shape[0]):
+        if torch.mean(gt[i]) == 0.0:
+            continue
+        prec, recall = avs_pr_curve(prob[i], gt[i], pr_num)
+        f = (1 + beta2) * prec * recall / (beta2 * prec + recall)
+        f[f != f] = 0
+        total = total + f
+        used += 1
+        score = total / used
+    return score.max().item()

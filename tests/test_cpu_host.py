@@ -138,3 +138,35 @@ def test_oracle_eval_steps_known_answers():
     x = O.sam_preprocess(img, 4)
     assert x.shape == (3, 4, 4) and float(x[:, 2:, :].abs().sum()) == 0 and float(x[:, :, 1:].abs().sum()) == 0
     assert abs(float(x[0, 0, 0]) - (0 - 123.675) / 58.395) < 1e-6 and abs(float(x[2, 1, 0]) - (128 - 103.53) / 57.375) < 1e-6
+
+
+def test_oracle_avs_metrics_known_answers():
+    """utils/pyutils.py:163-236 restatements against hand-computed values."""
+    import torch
+    from oracle import anyref_oracle as O
+    # mask 0: P = {0, 1}, G = {1, 2}: inter 1, union 3.   mask 1: empty G, P = {3}: 3 of 4 pixels agree -> 3 / 4
+    logits = torch.tensor([[[4.0, 2.0], [-2.0, -4.0]], [[-1.0, -1.0], [-1.0, 1.0]]])
+    gt = torch.tensor([[[0, 1], [1, 0]], [[0, 0], [0, 0]]])
+    want = (1 / 3 + 3 / 4) / 2
+    assert abs(float(O.avs_mask_iou(logits, gt)) - want) < 1e-6
+    # F-measure: only mask 0 counts.  Thresholds between sigmoid(-2) and sigmoid(2) pass pixels {0, 1}: tp 1,
+    # prec 1/2, recall 1/2 -> F = 1.3 * .25 / (.15 + .5); thresholds up to sigmoid(-2) pass {0, 1, 2}: tp 2, prec 2/3,
+    # recall 1 -> F = 1.3 * (2/3) / (0.2 + 1) = 0.7222 (the maximum)
+    f = O.avs_fmeasure(logits, gt.float())
+    assert abs(f - 1.3 * (2 / 3) / (0.3 * 2 / 3 + 1)) < 1e-6
+    assert O.avs_fmeasure(logits[1:], gt[1:].float()) == 0.0       # nothing but empty ground truths
+
+
+def test_avs_cut_logits_are_exact_crossovers():
+    """anyref_amd/evalops.py turns `sigmoid(x) >= th` into `x >= cut`: every cut must be the first passing f32."""
+    import torch
+    from anyref_amd import evalops as E
+    cuts, cut_pred = E._avs_cuts(255)
+    th = torch.linspace(0, 1 - 1e-10, 255)
+    assert cuts[0] == -float("inf") and bool((cuts[1:] > cuts[:-1]).all())
+    below = torch.nextafter(cuts[1:], torch.full_like(cuts[1:], -float("inf")))
+    pad = torch.zeros(64)                       # keeps the probes out of ATen's scalar end-of-tensor remainder
+    sig = lambda x: torch.sigmoid(torch.cat([x, pad]))[:x.numel()]
+    assert bool((sig(cuts[1:]) >= th[1:]).all()) and not bool((sig(below) >= th[1:]).any())
+    c = torch.tensor([cut_pred])
+    assert bool(sig(c) > 0.5) and not bool(sig(torch.nextafter(c, torch.tensor([-1.0]))) > 0.5)

@@ -70,3 +70,70 @@ def test_sam_preprocess_bit_exact(h, w, S):
     assert got.shape == want.shape and torch.equal(got, want)
     with pytest.raises(RuntimeError):
         sam_preprocess(torch.zeros(S + 1, 4, 3, dtype=torch.uint8).cuda(), S)
+
+
+# --- AVS metrics (utils/pyutils.py:163-236; eval_avs_object.py:168-178) ---------------------------------------
+def _avs_case(n, h, w, seed, scale=3.0, empty=()):
+    from anyref_amd import evalops as E
+    g = torch.Generator().manual_seed(seed)
+    logits = torch.randn(n, h, w, generator=g) * scale
+    gt = (torch.rand(n, h, w, generator=g) > 0.6).to(torch.int64)
+    for m in empty:
+        gt[m].zero_()
+    # plant the decision boundaries themselves: each cut and the float just below it
+    cuts, cut_pred = E._avs_cuts(255)
+    edge = torch.cat([cuts[1:], torch.nextafter(cuts[1:], torch.full_like(cuts[1:], -float("inf"))),
+                      torch.tensor([cut_pred, 0.0, -0.0, 1e-8, 30.0, -30.0, float("inf"), -float("inf")])])
+    flat = logits.view(n, -1)
+    if flat.shape[1] >= 2 * edge.numel():   # (torch's CPU sigmoid treats the last few elements of a tensor with scalar
+        for m in range(n):                  #  code that may round differently: keep the probes away from the end)
+            flat[m, :edge.numel()] = edge
+    return logits, gt
+
+
+@pytest.mark.parametrize("n,h,w", [(1, 224, 224), (5, 224, 224), (2, 333, 517), (1, 1, 7), (1, 1024, 1024)])
+def test_avs_mask_iou_and_fmeasure_match_reference_formulas(n, h, w):
+    from anyref_amd.evalops import mask_iou, eval_fmeasure
+    logits, gt = _avs_case(n, h, w, seed=n * 77 + w, empty=(n - 1,) if n > 1 else ())
+    got = mask_iou(logits.cuda(), gt.cuda())
+    want = O.avs_mask_iou(logits, gt)
+    assert got.dtype == want.dtype and float(got) == float(want), (got, want)      # same counts, same f32 ops
+    f_got = eval_fmeasure(logits.cuda(), gt.float().cuda(), None)
+    f_want = O.avs_fmeasure(logits, gt.float())
+    assert f_got == f_want, (f_got, f_want)
+
+
+def test_avs_counts_are_the_reference_threshold_sweep():
+    """every one of the 255 (tp, #passed) pairs of _eval_pr, not only the final maximum"""
+    from anyref_amd import evalops as E
+    logits, gt = _avs_case(2, 96, 128, seed=3, scale=6.0)
+    conf, hist = E._avs_counts(logits.cuda(), gt.cuda(), 255)
+    above = hist.flip(1).cumsum(1).flip(1)[:, 1:, :]
+    th = torch.linspace(0, 1 - 1e-10, 255)
+    prob = torch.sigmoid(logits)
+    for m in range(2):
+        for i in range(255):
+            passed = prob[m] >= th[i]
+            assert int(above[m, i].sum()) == int(passed.sum()), (m, i)
+            assert int(above[m, i, 1]) == int((passed & (gt[m] == 1)).sum()), (m, i)
+        p = torch.sigmoid(logits[m]) > 0.5
+        assert conf[m].tolist() == [int((~p & (gt[m] == 0)).sum()), int((~p & (gt[m] == 1)).sum()),
+                                    int((p & (gt[m] == 0)).sum()), int((p & (gt[m] == 1)).sum())]
+
+
+def test_avs_edge_cases():
+    from anyref_amd.evalops import mask_iou, eval_fmeasure
+    z = torch.zeros(2, 8, 8)
+    gt0 = torch.zeros(2, 8, 8, dtype=torch.int64)
+    assert float(mask_iou(z.cuda(), gt0.cuda())) == float(O.avs_mask_iou(z, gt0))        # all-empty ground truth
+    assert eval_fmeasure(z.cuda(), gt0.float().cuda()) == 0.0 == O.avs_fmeasure(z, gt0.float())
+    nan = torch.full((1, 4, 4), float("nan"))
+    g1 = torch.ones(1, 4, 4, dtype=torch.int64)
+    assert float(mask_iou(nan.cuda(), g1.cuda())) == float(O.avs_mask_iou(nan, g1))      # NaN passes no threshold
+    assert eval_fmeasure(nan.cuda(), g1.float().cuda()) == O.avs_fmeasure(nan, g1.float())
+    with pytest.raises(ValueError):
+        mask_iou(z.cuda(), (gt0 + 2).cuda())          # non-binary ground truth
+    with pytest.raises(ValueError):
+        mask_iou(z.cuda(), gt0[:, :4].cuda())
+    with pytest.raises(RuntimeError):
+        mask_iou(z, gt0)                              # host logits: no CPU fallback
