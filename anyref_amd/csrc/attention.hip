@@ -119,7 +119,11 @@ __device__ inline uint32_t pack_bf16x2(float lo, float hi) { return (uint32_t)f2
 // 7 x 80 for the 14 x 14 SAM windows (196 tokens: 2 query blocks x 3 key tiles per window-head where 4 x 64
 // needs 4 x 4 with the last of each nearly empty): 80 -> 73 us per window layer.  Measured alternatives:
 // 5 x 80 87 us, 4 x 80 123 us, 8 x 80 75 us, 7 x 64 78 us, 8 x 64 80 us (register-limited occupancy decides).
-template <typename T, int HD, int NWV = 4, int BKV_ = 0>
+// NRES > 0: ALL keys stay resident in LDS as NRES tiles of BKV (Sk <= NRES * BKV, one query block covers Sq): the
+// SAM windows again -- one workgroup per (window, head) loads K and V exactly once, a single barrier, then every
+// wave walks the resident tiles on its own (the streaming form ran two query blocks per window-head, each
+// re-loading K/V through three barrier-separated tiles at one workgroup per CU: 73 us per window layer).
+template <typename T, int HD, int NWV = 4, int BKV_ = 0, int NRES = 0>
 __global__ __launch_bounds__(NWV * 64) void attn_kernel(AttnArgs a) {
   constexpr int NT = NWV * 64;
   using M_ = AMma<T>;
@@ -138,9 +142,10 @@ __global__ __launch_bounds__(NWV * 64) void attn_kernel(AttnArgs a) {
   static_assert(HD % 16 == 0, "head dim must be a multiple of 16");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NTILE = NRES > 0 ? NRES : 1;  // tiles held in LDS
   T* Ks = reinterpret_cast<T*>(smem);
-  T* Vs = Ks + BKV * LDK;
-  float* relh_s = reinterpret_cast<float*>(Vs + BKV * LDV);
+  T* Vs = Ks + NTILE * BKV * LDK;
+  float* relh_s = reinterpret_cast<float*>(Vs + NTILE * BKV * LDV);
   float* relw_s = relh_s + BQ * a.kh;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -204,7 +209,7 @@ __global__ __launch_bounds__(NWV * 64) void attn_kernel(AttnArgs a) {
   }
   // global-attention fast path: the key tile is exactly one bias row (kw == BKV, tiles aligned), so
   // the kw-term of this lane's 16 keys never changes and the kh-term is one value per tile
-  const bool rel_fast = has_rel && a.kw == BKV;
+  const bool rel_fast = NRES == 0 && has_rel && a.kw == BKV;  // (compile-time off for the resident form: registers)
   // general path: j / kw by multiply-shift, exact for j < 4096 and kw <= 64 (error j / 2^20 < 1 / kw)
   const unsigned kw_magic = has_rel ? (1u << 20) / (unsigned)a.kw + 1u : 0u;
   float relw_reg[NB][4];
@@ -242,15 +247,15 @@ __global__ __launch_bounds__(NWV * 64) void attn_kernel(AttnArgs a) {
                                                : uint4v{0, 0, 0, 0};
     }
   };
-  auto sstore_tile = [&]() {
+  auto sstore_tile = [&](int slot = 0) {
 #pragma unroll
     for (int i = 0; i < KPT; ++i) {
-      const int v = tid + i * NT, row = v / KVEC, d = (v % KVEC) * VEC;
+      const int v = tid + i * NT, row = slot * BKV + v / KVEC, d = (v % KVEC) * VEC;
       if (v < BKV * KVEC) *reinterpret_cast<uint4v*>(&Ks[row * LDK + d]) = kreg[i];
     }
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
-      const int v = tid + i * NT, row = v / VVEC, d = (v % VVEC) * VEC;
+      const int v = tid + i * NT, row = slot * BKV + v / VVEC, d = (v % VVEC) * VEC;
       if (v < BKV * VVEC) *reinterpret_cast<uint4v*>(&Vs[row * LDV + d]) = vreg[i];
     }
   };
@@ -260,11 +265,25 @@ __global__ __launch_bounds__(NWV * 64) void attn_kernel(AttnArgs a) {
     kt_begin = split * chunk;
     kv_end = kv_end < kt_begin + chunk ? kv_end : kt_begin + chunk;
   }
-  if (kv_end > kt_begin) gload_tile(kt_begin);
-  for (int kt = kt_begin; kt < kv_end; kt += BKV) {
-    sstore_tile();
+  if constexpr (NRES > 0) {
+#pragma unroll
+    for (int t = 0; t < NRES; ++t)
+      if (t * BKV < kv_end) {
+        gload_tile(t * BKV);
+        sstore_tile(t);
+      }
     __syncthreads();
-    if (kt + BKV < kv_end) gload_tile(kt + BKV);
+  } else {
+    if (kv_end > kt_begin) gload_tile(kt_begin);
+  }
+  for (int kt = kt_begin; kt < kv_end; kt += BKV) {
+    const int slot = NRES > 0 ? kt / BKV : 0;  // resident tile of this step
+    const T* Kt = Ks + slot * BKV * LDK;
+    if constexpr (NRES == 0) {
+      sstore_tile();
+      __syncthreads();
+      if (kt + BKV < kv_end) gload_tile(kt + BKV);
+    }
 
     // wave-uniform skips: rows past the end / tile entirely in the causal future of this row block
     const bool active = q0 + wave * 16 < q_len && !(a.causal && kt > pos0 + q0 + wave * 16 + 15);
@@ -276,7 +295,7 @@ __global__ __launch_bounds__(NWV * 64) void attn_kernel(AttnArgs a) {
         st[nb] = float4v{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < HDK / KS; ++kk)
-          st[nb] = M_::mma(M_::lds(&Ks[(nb * 16 + qi) * LDK + kk * KS], lane), qf[kk], st[nb]);
+          st[nb] = M_::mma(M_::lds(&Kt[(nb * 16 + qi) * LDK + kk * KS], lane), qf[kk], st[nb]);
       }
       if constexpr (!BF) {
         // hipcc/ROCm 7.2 under-pads the VALU read of a v_mfma_f32_16x16x4_f32 result on gfx950
@@ -378,7 +397,7 @@ __global__ __launch_bounds__(NWV * 64) void attn_kernel(AttnArgs a) {
       if constexpr (BF) {
         // this lane's address inside its group's 4x16 block: row q = (lane&15)>>2, columns 4p
         const uint32_t vbase = (uint32_t)(reinterpret_cast<const char*>(Vs) - smem) +  // dynamic LDS starts at 0
-                               (uint32_t)((4 * g + (qi >> 2)) * LDV + 4 * (qi & 3)) * 2u;
+                               (uint32_t)((slot * BKV + 4 * g + (qi >> 2)) * LDV + 4 * (qi & 3)) * 2u;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
           uint2v vt[DB];
@@ -395,13 +414,13 @@ __global__ __launch_bounds__(NWV * 64) void attn_kernel(AttnArgs a) {
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float* vrow = reinterpret_cast<const float*>(Vs) + (nb * 16 + 4 * g + r) * LDV + qi;  // k-slot g <- key 4g+r
+            const float* vrow = reinterpret_cast<const float*>(Vs) + (slot * BKV + nb * 16 + 4 * g + r) * LDV + qi;  // k-slot g <- key 4g+r
 #pragma unroll
             for (int d = 0; d < DB; ++d) ot[d] = M_::mma(vrow[d * 16], sv[nb][r], ot[d]);
           }
       }
     }
-    __syncthreads();  // K/V tiles free for the next iteration
+    if constexpr (NRES == 0) __syncthreads();  // K/V tiles free for the next iteration
   }
 
   // ---- normalise + store: lane (query qi, group g) holds O[query][d = 16*db + 4g + r] ------------
@@ -487,18 +506,20 @@ static float* attn_workspace(hipStream_t s, size_t bytes) {
   return w.p;
 }
 
-template <typename T, int HD, int NWV, int BKVP>
+template <typename T, int HD, int NWV, int BKVP, int NRES = 0>
 static void attn_launch_cfg(const AttnArgs& a_in, hipStream_t s) {
   AttnArgs a = a_in;
   constexpr int KS = AMma<T>::KS, VEC = AMma<T>::VEC, BKV = BKVP > 0 ? BKVP : AttnTile<T>::BKV, BQ = 16 * NWV;
   constexpr int HDK = (HD + KS - 1) / KS * KS, LDK = HDK + VEC;
   constexpr int LDV = sizeof(T) == 2 ? ((HD * 2 + 255) / 256 * 256 + 32) / 2 : HD + VEC;
-  size_t lds = sizeof(T) * (BKV * LDK + BKV * LDV);
+  size_t lds = sizeof(T) * (BKV * LDK + BKV * LDV) * (NRES > 0 ? NRES : 1);
+  if (NRES > 0 && (a.Sk > NRES * BKV || a.Sq > BQ || a.kv_len || a.causal))
+    throw std::runtime_error("attention: resident-key form needs Sk <= NRES * BKV and one query block");
   if (a.rel_h || a.rel_p) lds += sizeof(float) * BQ * (a.kh + a.kw);
   if (lds > 160 * 1024) throw std::runtime_error("attention: LDS budget exceeded");
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<T, HD, NWV, BKVP>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<T, HD, NWV, BKVP, NRES>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
@@ -518,11 +539,11 @@ static void attn_launch_cfg(const AttnArgs& a_in, hipStream_t s) {
   }
   dim3 grid(cdiv(a.Sq, BQ) * a.kv_splits, a.H, a.B);
   static const std::string tag = std::string(sizeof(T) == 2 ? "attn_bf16_hd" : "attn_f32_hd") + std::to_string(HD) +
-                                 (NWV == 4 ? "" : "_w" + std::to_string(NWV));
+                                 (NWV == 4 ? "" : "_w" + std::to_string(NWV)) + (NRES > 0 ? "_res" : "");
   const double flops = 4.0 * a.B * a.H * (double)a.Sq * a.Sk * HD * (a.causal ? 0.5 : 1.0);
   const double bytes = (double)a.B * a.H * HD * sizeof(T) * (2.0 * a.Sq + 2.0 * a.Sk);
   ProfScope prof(tag.c_str(), flops, bytes, s);
-  hipLaunchKernelGGL((attn_kernel<T, HD, NWV, BKVP>), grid, dim3(NWV * 64), lds, s, a);
+  hipLaunchKernelGGL((attn_kernel<T, HD, NWV, BKVP, NRES>), grid, dim3(NWV * 64), lds, s, a);
   if (a.kv_splits > 1) {
     const int64_t n = (int64_t)a.B * a.H * a.Sq * HD;
     hipLaunchKernelGGL((attn_combine_kernel<T>), dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s, a, HD);
@@ -531,8 +552,15 @@ static void attn_launch_cfg(const AttnArgs& a_in, hipStream_t s) {
 
 template <typename T, int HD>
 static void attn_launch(const AttnArgs& a, hipStream_t s) {
-  // SAM windows (14 x 14 = 196 tokens, bf16, head dim 80): 7 waves x 80 keys tile the window 2 x 3
+  // SAM windows (14 x 14 = 196 tokens, bf16, head dim 80): one workgroup of 13 waves per (window, head) with all
+  // keys resident as 5 tiles of 48 (48: the largest tile that stays under the 128 VGPRs 13 waves leave without
+  // spilling -- 64 x 4 spills 8 dwords, 80 x 3 spills 31).  73.7 -> 47.5 us per window layer.  Other 193..240
+  // token windows keep the streaming 7 waves x 80 keys form (2 x 3 tiles).
   if constexpr (sizeof(T) == 2 && HD == 80) {
+    if (a.Sq == a.Sk && a.Sq > 192 && a.Sq <= 208 && !a.causal && !a.kv_len && !a.q_len) {
+      attn_launch_cfg<T, HD, 13, 48, 5>(a, s);
+      return;
+    }
     if (a.Sq == a.Sk && a.Sq > 192 && a.Sq <= 240 && !a.causal) {
       attn_launch_cfg<T, HD, 7, 80>(a, s);
       return;
