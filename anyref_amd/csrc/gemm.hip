@@ -581,6 +581,7 @@ struct GemmKnobs {
   int gm = getenv("ANYREF_GEMM_GM") ? atoi(getenv("ANYREF_GEMM_GM")) : -1;
   int tile = getenv("ANYREF_GEMM_TILE") ? atoi(getenv("ANYREF_GEMM_TILE")) : -1;
   int gemv_grid = getenv("ANYREF_GEMV_GRID") ? atoi(getenv("ANYREF_GEMV_GRID")) : 0;
+  int force128 = getenv("ANYREF_GEMM_FORCE128") ? atoi(getenv("ANYREF_GEMM_FORCE128")) : 0;  // probe: 3 = 128^2 NS3, 2 = NS2
 };
 static const GemmKnobs& knobs() {
   static const GemmKnobs k;
@@ -735,7 +736,11 @@ void launch_gemm(const GemmArgs& a_in, hipStream_t s) {
       using I320 = std::integral_constant<int, 320>;
       const int64_t t320 = (int64_t)cdiv(a.M, 256) * cdiv(a.N, 320) * a.batch;
       const double fill320 = (double)t320 / (double)(cdiv64(t320, cus) * cus);
-      if (a.M >= 1024 && fill256 >= 0.85)
+      if (a.M >= 1024 && knobs().force128 == 3)
+        go(I128(), I128(), I2(), I4(), I3(), "gemm_bf16_128x128s3");
+      else if (a.M >= 1024 && knobs().force128 == 2)
+        go(I128(), I128(), I2(), I4(), I2(), "gemm_bf16_128x128g");
+      else if (a.M >= 1024 && fill256 >= 0.85)
         go(I256(), I256(), I2(), I4(), I2(), "gemm_bf16_256x256");
       else if (!a.w_fp8 && a.M >= 1024 && a.N % 320 == 0 && fill320 >= 0.95)
         go(I256(), I320(), I2(), I4(), I2(), "gemm_bf16_256x320");  // SAM fc1: 16 x 16 tiles = one per CU
@@ -787,7 +792,10 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int b0, int nb) {
   constexpr int VN = W8 ? 16 : Vec16<T>::N;  // weights per 16-byte load
   constexpr int R = DUAL ? 1 : 2;   // output rows per wave per pass
   constexpr int RW = 2;             // weight rows streamed per pass (DUAL: gate row + up row)
-  constexpr int UNR = 4;            // 16-byte loads per row in flight per lane (8 measured slower)
+  // 16-byte loads per row in flight per lane.  8 measured slower; 2 (68 instead of 100 VGPRs, so that a GEMV
+  // workgroup fits beside a resident 256^2 GEMM workgroup of the co-running SAM stream) measured equal within
+  // noise, alone and under the overlap
+  constexpr int UNR = 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* xs = reinterpret_cast<T*>(smem);  // [NB][K]
   __shared__ float red[NB][8];
