@@ -319,10 +319,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs a) {
   constexpr int WROWB = W8 ? BK : BK * 2;  // bytes per W tile row
   constexpr int WRPI = W8 ? 16 : 8;        // W rows per wave DMA instruction
   constexpr int TILEB = BM * ROWB + BN * WROWB;  // one stage
-  constexpr int RA = BM / (NW * 8), RW = BN / (NW * WRPI);  // LDS-DMA rounds
-  constexpr int LPT = RA + RW;                           // DMA instructions per lane per tile
-  static_assert(BM % (NW * 8) == 0 && BN % (NW * WRPI) == 0, "tile rows must split over the waves");
-  static_assert(NS >= 2 && NS <= 4 && (NS - 2) * LPT <= 63, "stage count / vmcnt range");
+  // LDS-DMA rounds: RA / RWF full rounds of all NW waves; a BN that is not a multiple of NW * WRPI rows adds a
+  // last round that only waves 0 .. PW-1 take part in (128 x 160: 256 equal tiles for SAM fc2, 4096 x 1280)
+  constexpr int RA = BM / (NW * 8), RWF = BN / (NW * WRPI), PW = (BN % (NW * WRPI)) / WRPI, RW = RWF + (PW > 0);
+  constexpr int LPT = RA + RWF;                          // DMA instructions per lane per tile (+1 on waves < PW)
+  static_assert(BM % (NW * 8) == 0 && BN % WRPI == 0 && (PW == 0 || !W8), "tile rows must split over the waves");
+  static_assert(NS >= 2 && NS <= 4 && (NS - 2) * (LPT + 1) <= 63, "stage count / vmcnt range");
   extern __shared__ __attribute__((aligned(1024))) char smem[];  // the ONLY LDS object (rule: one array)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave / WN, wc = wave % WN;
@@ -396,8 +398,19 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs a) {
                                        0);
 #pragma unroll
     for (int r = 0; r < RW; ++r)
-      __builtin_amdgcn_global_load_lds((gas_ptr)(wsrc[r] + t * BK),
-                                       (las_ptr)(base + BM * ROWB + (r * NW + wave) * WRPI * WROWB), 16, 0, 0);
+      if (r < RWF || wave < PW)  // (wave-uniform)
+        __builtin_amdgcn_global_load_lds((gas_ptr)(wsrc[r] + t * BK),
+                                         (las_ptr)(base + BM * ROWB + (r * NW + wave) * WRPI * WROWB), 16, 0, 0);
+  };
+  // wait until at most N tiles' worth of this wave's own DMAs are still in flight
+  auto wait_tiles = [&](auto n_c) {
+    constexpr int N = decltype(n_c)::value;
+    if constexpr (PW == 0 || N == 0) {
+      wait_vmcnt<N * LPT>();
+    } else {
+      if (wave < PW) wait_vmcnt<N * (LPT + 1)>();
+      else wait_vmcnt<N * LPT>();
+    }
   };
   auto compute = [&](auto buf_c) {
     constexpr int buf = decltype(buf_c)::value;
@@ -442,9 +455,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs a) {
       if (t < nt) {
         // own DMAs of tile t have landed once at most min(NS-2, nt-1-t) younger tiles are still in flight
         const int behind = nt - 1 - t;
-        if (behind >= NS - 2) wait_vmcnt<(NS - 2) * LPT>();
-        else if (NS > 3 && behind == 1) wait_vmcnt<LPT>();
-        else wait_vmcnt<0>();
+        if (behind >= NS - 2) wait_tiles(std::integral_constant<int, NS - 2>());
+        else if (NS > 3 && behind == 1) wait_tiles(std::integral_constant<int, 1>());
+        else wait_tiles(std::integral_constant<int, 0>());
         __builtin_amdgcn_s_barrier();  // ... and so have everyone else's; all waves are done with tile t-1
         if (t + NS - 1 < nt) stage(std::integral_constant<int, (B + NS - 1) % NS>(), t + NS - 1);  // into t-1's buffer
         compute(b);
@@ -734,6 +747,10 @@ void launch_gemm(const GemmArgs& a_in, hipStream_t s) {
       const int64_t t64w = (int64_t)cdiv(a.M, 64) * cdiv(a.N, 256) * a.batch;
       const int64_t t128 = (int64_t)cdiv(a.M, 128) * cdiv(a.N, 128) * a.batch;
       using I320 = std::integral_constant<int, 320>;
+      using I160 = std::integral_constant<int, 160>;
+      const int64_t t160 = (int64_t)cdiv(a.M, 128) * cdiv(a.N, 160) * a.batch;
+      const double fill160 = (double)t160 / (double)(cdiv64(t160, cus) * cus);
+      const double fill128 = (double)t128 / (double)(cdiv64(t128, cus) * cus);
       const int64_t t320 = (int64_t)cdiv(a.M, 256) * cdiv(a.N, 320) * a.batch;
       const double fill320 = (double)t320 / (double)(cdiv64(t320, cus) * cus);
       if (a.M >= 1024 && knobs().force128 == 3)
@@ -744,6 +761,8 @@ void launch_gemm(const GemmArgs& a_in, hipStream_t s) {
         go(I256(), I256(), I2(), I4(), I2(), "gemm_bf16_256x256");
       else if (!a.w_fp8 && a.M >= 1024 && a.N % 320 == 0 && fill320 >= 0.95)
         go(I256(), I320(), I2(), I4(), I2(), "gemm_bf16_256x320");  // SAM fc1: 16 x 16 tiles = one per CU
+      else if (!a.w_fp8 && a.M >= 1024 && a.N % 160 == 0 && fill160 >= 0.95 && fill128 < 0.7)
+        go(I128(), I160(), I4(), I2(), I3(), "gemm_bf16_128x160s3");  // SAM fc2: 32 x 8 tiles = one per CU
       else if (a.M <= 512 && a.N >= 8192) {
         if (t64w <= cus) go(I64(), I256(), I1(), I4(), I3(), "gemm_bf16_64x256s3");
         else go(I64(), I256(), I1(), I4(), I2(), "gemm_bf16_64x256");

@@ -75,6 +75,20 @@ def test_gemm(lib, ty, M, N, K, act):
     close(out, ref, TOL[ty] * 4)
 
 
+@pytest.mark.parametrize("M,N,K", [(4096, 3840, 128), (4096, 5120, 128), (4096, 1280, 192), (4096, 1280, 64),
+                                   (4096, 1280, 448), (320, 12288, 128), (320, 22016, 192), (4900, 1280, 128)])
+def test_gemm_tile_paths_of_the_big_shapes(lib, M, N, K):
+    """the tile heuristics of launch_gemm at the SAM-H / LLaMA-7B output shapes (short K): 256^2, 256x320,
+    128x160 (ragged LDS-DMA round, 1 .. 7 K tiles through the 3-stage ring), 64x256 with 3 / 2 stages, 128^2"""
+    g = torch.Generator().manual_seed(M + N + K)
+    A, W = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.1
+    bias = torch.randn(N, generator=g)
+    ref = rnd(A, 1) @ rnd(W, 1).t() + bias
+    out = torch.empty(M, N, device="cuda")
+    check(lib, lib.anyref_op_gemm(1, None, P(dev(A, 1)), P(dev(W, 1)), P(bias.cuda()), P(out), None, None, M, N, K, 0, 1))
+    close(out, ref, 1e-4)            # bf16 products are exact in f32; only the summation order differs
+
+
 @pytest.mark.parametrize("ty", [0, 1])
 def test_gemm_row_map_and_typed_out(lib, ty):
     M, N, K = 200, 96, 64
