@@ -1,0 +1,36 @@
+#!/bin/bash
+# Collect the round's profile evidence on the GPU box (run from the repo root through gpurun):
+#   tools/collect_profiles.sh gpurun_out/v7
+# Raw rocprofv3 output goes to /tmp (hundreds of MB); only the summaries land in the output directory, which is
+# then copied into profiles/ by hand.  Kernel trace / stats and the PMC passes are SEPARATE runs (a combined run is
+# refused on this pool), and the program comes directly after `--`.
+set -o pipefail
+OUT=${1:-gpurun_out/prof}
+R=$(pwd)
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+W=/tmp/anyref_prof; rm -rf $W; mkdir -p $W
+python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.err" || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $W/kt -o kt -- python3 bench.py --no-cpu-baseline --no-parity > $W/kt.json 2> $W/kt.err || exit 2
+cp $W/kt/kt_kernel_stats.csv "$OUT/kt_kernel_stats.csv" 2>/dev/null || cp $(ls $W/kt/*/*kernel_stats.csv | head -1) "$OUT/kt_kernel_stats.csv"
+rocprofv3 --kernel-trace --stats --output-format csv -d $W/pd -o pd -- python3 scratch/prof_decode.py > /dev/null 2>&1 || exit 3
+cp $W/pd/pd_kernel_stats.csv "$OUT/pd_kernel_stats.csv" 2>/dev/null || cp $(ls $W/pd/*/*kernel_stats.csv | head -1) "$OUT/pd_kernel_stats.csv"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $W/pmc_fetch -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-parity > $W/pf.json 2> $W/pf.err || exit 4
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $W/pmc_write -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-parity > $W/pw.json 2> $W/pw.err || exit 5
+python3 tools/pmc_summary.py $W/pmc_fetch $W/pmc_write "$OUT/pmc_traffic.json" > /dev/null || exit 6
+python3 - "$W" "$OUT" <<'PY'
+import collections, csv, glob, sys
+w, out = sys.argv[1], sys.argv[2]
+for d, c in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+    agg = collections.defaultdict(lambda: [0.0, 0])
+    for f in glob.glob(f"{w}/{d}/*/*_counter_collection.csv"):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == c:
+                k = r["Kernel_Name"].split("(")[0]
+                agg[k][0] += float(r["Counter_Value"]); agg[k][1] += 1
+    with open(f"{out}/pmc_{c.lower()}_per_kernel.csv", "w") as fo:
+        fo.write(f"kernel,launches,{c}_KiB_sum,{c}_KiB_per_launch\n")
+        for k, (s, n) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
+            fo.write(f"\"{k}\",{n},{round(s, 1)},{round(s / n, 2)}\n")
+PY
+ls -la "$OUT"

@@ -19,12 +19,13 @@ TAGS = {  # bench.py roofline tag -> kernel-name prefix
     "gemv_bf16_x8": "gemv_kernel<anyref::bf16, 1, false, 8, false>",
     "gemv_bf16_x24": "gemv_kernel<anyref::bf16, 1, false, 24, false>",
     "gemv_bf16_swiglu_x8": "gemv_kernel<anyref::bf16, 1, true, 8, false>",
-    "gemm_bf16_256x256": "gemm_glds_kernel<256, 256, 2, 4, 2>",
-    "gemm_bf16_256x320": "gemm_glds_kernel<256, 320, 2, 4, 2>",
-    "gemm_bf16_128x128g": "gemm_glds_kernel<128, 128, 2, 4, 2>",
-    "gemm_bf16_128x128s3": "gemm_glds_kernel<128, 128, 2, 4, 3>",
-    "gemm_bf16_64x256": "gemm_glds_kernel<64, 256, 1, 4, 2>",
-    "gemm_bf16_64x256s3": "gemm_glds_kernel<64, 256, 1, 4, 3>",
+    "gemm_bf16_256x256": "gemm_glds_kernel<256, 256, 2, 4, 2, false>",
+    "gemm_bf16_256x320": "gemm_glds_kernel<256, 320, 2, 4, 2, false>",
+    "gemm_bf16_128x128g": "gemm_glds_kernel<128, 128, 2, 4, 2, false>",
+    "gemm_bf16_128x128s3": "gemm_glds_kernel<128, 128, 2, 4, 3, false>",
+    "gemm_bf16_64x256": "gemm_glds_kernel<64, 256, 1, 4, 2, false>",
+    "gemm_bf16_64x256s3": "gemm_glds_kernel<64, 256, 1, 4, 3, false>",
+    "gemm_bf16_128x160s3": "gemm_glds_kernel<128, 160, 4, 2, 3, false>",
     "gemm_bf16_128x128": "gemm_kernel<anyref::bf16, 128, 128, 64>",
     "gemm_bf16_64x128": "gemm_kernel<anyref::bf16, 64, 128, 64>",
     "gemm_bf16_64x64": "gemm_kernel<anyref::bf16, 64, 64, 64>",
