@@ -32,6 +32,7 @@ int anyref_op_gemm(int t, void* stream, const void* A, const void* W, const floa
     GemmArgs a;
     a.A = A; a.lda = K; a.W = W; a.ldw = K; a.bias = bias; a.C = C; a.ldc = N; a.resid = resid; a.ldr = N;
     a.row_map = row_map; a.M = M; a.N = N; a.K = K; a.act = act; a.c_f32 = c_f32;
+    if (const char* e = getenv("ANYREF_OPTEST_LDW_PAD")) a.ldw = K + atoi(e);  // probe: padded weight rows
     if (t == 0) launch_gemm<float>(a, (hipStream_t)stream); else launch_gemm<bf16>(a, (hipStream_t)stream);
   });
 }

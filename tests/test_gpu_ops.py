@@ -175,6 +175,10 @@ def ref_attention(q, k, v, scale, causal, kv_len, rel_h, rel_w, kw):
     (2, 2, 100, 130, 80, 0),      # hd 80, Sq != Sk
     (1, 8, 7, 4096, 16, 0),       # SAM-H mask decoder token -> image: keys split over workgroups + merge
     (1, 4, 70, 2500, 32, 0),      # two query blocks, ragged key splits
+    (1, 5, 196, 196, 80, 0),      # SAM window without bias: keys resident in LDS (13 waves, 5 tiles of 48)
+    (1, 3, 205, 205, 80, 0),      # same form, last tile and last query block ragged
+    (1, 3, 230, 230, 80, 0),      # 193..240 tokens beyond the resident form: streaming 7 waves x 80 keys
+    (2, 2, 200, 200, 80, 0),      # kv_len given: falls back to the streaming form
 ])
 def test_attention(lib, ty, B, H, Sq, Sk, hd, causal):
     g = torch.Generator().manual_seed(Sq * 3 + Sk + hd)
