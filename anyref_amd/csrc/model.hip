@@ -251,7 +251,8 @@ class Model : public ModelBase {
   void clip_tower(hipStream_t s, const float* images, int B);  // -> img_feat_ [B,n,H]
   void llm_prefill(hipStream_t s, int B, int Sp, const int* lens_dev, bool keep_q);
   void llm_decode_step(hipStream_t s, int B, bool keep_q);
-  void sam_encoder(hipStream_t s, const float* images, int B, float* out);
+  // blocks [blk0, blk1) of the encoder; blk0 == 0 also runs the patch embedding, blk1 < 0 (= to the end) the neck
+  void sam_encoder(hipStream_t s, const float* images, int B, float* out, int blk0 = 0, int blk1 = -1);
   void mask_decoder(hipStream_t s, const float* image_emb, const float* pred_emb, int n, float* masks4,
                     float* iou);
   void run_tail(hipStream_t s, const float* sam_images, int B, const std::vector<int>& seg_b,
@@ -261,6 +262,9 @@ class Model : public ModelBase {
   // SAM image encoder on a second stream: it depends on nothing but the image, is MFMA-bound, and
   // overlaps the HBM-bound LLM decode (fork at the start of a call, join before the mask decoder).
   void fork_sam(hipStream_t s, const float* sam_images, int B);
+  void fork_sam_head(hipStream_t s, const float* sam_images, int B);
+  int sam_head_blocks_ = getenv("ANYREF_SAM_HEAD_BLOCKS") ? atoi(getenv("ANYREF_SAM_HEAD_BLOCKS")) : 0;
+  bool sam_head_done_ = false;
   hipStream_t s2_ = nullptr;
   hipEvent_t ev_fork_ = nullptr, ev_sam_ = nullptr;
   bool sam_forked_ = false;
@@ -836,9 +840,19 @@ void Model<T>::fork_sam(hipStream_t s, const float* sam_images, int B) {
   if (!overlap_) return;  // encoder then runs on `s` inside run_tail
   HIP_TRY(hipEventRecord(ev_fork_, s));
   HIP_TRY(hipStreamWaitEvent(s2_, ev_fork_, 0));
-  sam_encoder(s2_, sam_images, B, sam_emb_);
+  sam_encoder(s2_, sam_images, B, sam_emb_, sam_head_done_ ? sam_head_blocks_ : 0, -1);
   HIP_TRY(hipEventRecord(ev_sam_, s2_));
   sam_forked_ = true;
+  sam_head_done_ = false;
+}
+// The first blocks of the encoder beside the CLIP tower (257 tokens: ~220 short launches that leave most CUs idle)
+template <typename T>
+void Model<T>::fork_sam_head(hipStream_t s, const float* sam_images, int B) {
+  if (!overlap_ || sam_head_blocks_ <= 0) return;
+  HIP_TRY(hipEventRecord(ev_fork_, s));
+  HIP_TRY(hipStreamWaitEvent(s2_, ev_fork_, 0));
+  sam_encoder(s2_, sam_images, B, sam_emb_, 0, sam_head_blocks_);
+  sam_head_done_ = true;
 }
 
 template <typename T>
@@ -1087,12 +1101,15 @@ void Model<T>::llm_forward(hipStream_t s, const float* embeds, const int32_t* le
 // SAM image encoder
 // ---------------------------------------------------------------------------------------------
 template <typename T>
-void Model<T>::sam_encoder(hipStream_t s, const float* images, int B, float* out) {
+void Model<T>::sam_encoder(hipStream_t s, const float* images, int B, float* out, int blk0, int blk1) {
   const anyref_config& c = cfg;
   const int D = c.sam_dim, g = sam_g_, NT = g * g, RT = B * NT, ws = c.sam_window, nh = c.sam_heads, hd = D / nh;
   const int C = c.sam_out_chans, WR = sam_wrows_, nW = sam_nw_ * sam_nw_;
-  launch_im2col_patch<T>(images, B, c.sam_img, c.sam_patch, s_col_, sam_patch_.k, s);
-  {
+  const int nblk = (int)sam_blocks_.size();
+  const bool to_end = blk1 < 0 || blk1 >= nblk;
+  if (to_end) blk1 = nblk;
+  if (blk0 == 0) {
+    launch_im2col_patch<T>(images, B, c.sam_img, c.sam_patch, s_col_, sam_patch_.k, s);
     GemmArgs a;
     a.A = s_col_; a.lda = sam_patch_.k; a.W = sam_patch_.w; a.ldw = sam_patch_.k; a.bias = sam_patch_.b;
     a.C = s_x_; a.ldc = D; a.M = NT; a.N = D; a.K = sam_patch_.k; a.c_f32 = 1;
@@ -1100,7 +1117,8 @@ void Model<T>::sam_encoder(hipStream_t s, const float* images, int B, float* out
     a.batch = B; a.sA = (int64_t)NT * sam_patch_.k; a.sC = (int64_t)NT * D; a.sR = 0;
     launch_gemm<T>(a, s);
   }
-  for (auto& L : sam_blocks_) {
+  for (int bi = blk0; bi < blk1; ++bi) {
+    auto& L = sam_blocks_[bi];
     AttnArgs a;
     a.q_hs = a.k_hs = a.v_hs = hd; a.o_hs = hd;
     a.q_rs = a.k_rs = a.v_rs = 3 * D; a.o_rs = D;
@@ -1142,6 +1160,7 @@ void Model<T>::sam_encoder(hipStream_t s, const float* images, int B, float* out
     gemm(s, s_hglob_, D, L.lin1, s_mlp_, c.sam_mlp_ratio * D, RT, ACT_GELU, false);
     gemm(s, s_mlp_, c.sam_mlp_ratio * D, L.lin2, s_x_, D, RT, ACT_NONE, true, s_x_, D);
   }
+  if (!to_end) return;
   // neck: 1x1 conv -> LN2d -> 3x3 conv -> LN2d (channels-last tokens; fp32 LayerNorm as the
   // reference forces under fp16, image_encoder.py:119-122)
   launch_convert<T>(s_x_, D, s_hglob_, D, RT, D, s);
@@ -1412,6 +1431,8 @@ void Model<T>::generate(hipStream_t s, const float* clip_images, const float* sa
   const int H = c.llm_dim, S = c.llm_max_seq, n_img = clip_n_;
   const bool keep_q = c.rephrase_weight > 0.f;
 
+  sam_head_done_ = false;
+  fork_sam_head(s, sam_images, B);
   clip_tower(s, clip_images, B);
   std::vector<int> slen, img_pos;
   const int Sp = splice_inputs(s, input_ids, lens, B, Lmax, extra_embeds, extra_slots, n_extra, slen, img_pos);
@@ -1496,6 +1517,7 @@ void Model<T>::forward_teacher(hipStream_t s, const float* clip_images, const fl
   if (B <= 0 || B > c.max_batch) throw std::runtime_error("batch exceeds max_batch");
   const int H = c.llm_dim, S = c.llm_max_seq, n_img = clip_n_;
   const bool keep_q = c.rephrase_weight > 0.f;
+  sam_head_done_ = false;
   fork_sam(s, sam_images, B);
   clip_tower(s, clip_images, B);
   std::vector<int> slen, img_pos;
