@@ -196,7 +196,7 @@ def test_attention(lib, ty, B, H, Sq, Sk, hd, causal):
 
 
 @pytest.mark.parametrize("ty", [0, 1])
-@pytest.mark.parametrize("B,H,size,hd", [(3, 2, 14, 80), (1, 2, 16, 64), (2, 3, 4, 64)])
+@pytest.mark.parametrize("B,H,size,hd", [(3, 2, 14, 80), (1, 2, 16, 64), (2, 3, 4, 64), (1, 2, 64, 80), (1, 1, 32, 80)])
 def test_sam_attention_rel_pos(lib, ty, B, H, size, hd):
     """windowed / global SAM attention incl. the decomposed rel-pos bias (image_encoder.py:231-392)."""
     g = torch.Generator().manual_seed(size + hd)

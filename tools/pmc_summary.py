@@ -30,6 +30,7 @@ TAGS = {  # bench.py roofline tag -> kernel-name prefix
     "gemm_bf16_64x128": "gemm_kernel<anyref::bf16, 64, 128, 64>",
     "gemm_bf16_64x64": "gemm_kernel<anyref::bf16, 64, 64, 64>",
     "attn_bf16_hd80": "attn_kernel<anyref::bf16, 80, 4, 0, 0>",
+    "attn_bf16_hd80_w8": "attn_kernel<anyref::bf16, 80, 8, 64, 0>",
     "attn_bf16_hd80_w13_res": "attn_kernel<anyref::bf16, 80, 13, 48, 5>",
     "attn_bf16_hd128": "attn_kernel<anyref::bf16, 128, 4, 0, 0>",
     "decode_attn_bf16": "decode_attn_kernel<anyref::bf16, 128>",
