@@ -181,8 +181,27 @@ __global__ __launch_bounds__(NWV * 64) void attn_kernel(AttnArgs a) {
   // bf16 path: softmax in the log2 domain (one v_exp_f32 per score): scores and biases carry log2(e)
   constexpr float LOG2E = 1.4426950408889634f;
   const float bsc = BF ? LOG2E : 1.f;
-  const bool has_rel = a.rel_h != nullptr || a.rel_p != nullptr;
-  if (a.rel_p) {
+  bool rel_tab = false;  // tables given: bias computed here (resident form, bf16)
+  if constexpr (NRES > 0 && BF) rel_tab = a.rel_tab_h != nullptr;
+  const bool has_rel = a.rel_h != nullptr || a.rel_p != nullptr || rel_tab;
+  T* Rs = reinterpret_cast<T*>(relw_s + BQ * a.kw);  // [2][32][LDK] zero-padded tables (rel_tab only)
+  if constexpr (NRES > 0 && BF) {
+    if (rel_tab) {
+      for (int i = tid; i < BQ * (a.kh + a.kw); i += NT) relh_s[i] = 0.f;  // relw_s follows relh_s
+      constexpr int RV = LDK / VEC;
+      for (int i = tid; i < 2 * 32 * RV; i += NT) {
+        const int t = i / (32 * RV), e = (i / RV) % 32, d = (i % RV) * VEC;
+        const int ne = 2 * (t == 0 ? a.kh : a.kw) - 1;
+        const T* tab = reinterpret_cast<const T*>(t == 0 ? a.rel_tab_h : a.rel_tab_w);
+        const uint4v v = (e < ne && d < HD) ? *reinterpret_cast<const uint4v*>(tab + (int64_t)e * a.rel_tab_ld + d)
+                                            : uint4v{0, 0, 0, 0};
+        *reinterpret_cast<uint4v*>(&Rs[(t * 32 + e) * LDK + d]) = v;
+      }
+    }
+  }
+  if (rel_tab) {
+    // filled after the K/V barrier below
+  } else if (a.rel_p) {
     const float* P = a.rel_p + (int64_t)h * a.rel_hs + ((int64_t)b * a.Sq + q0) * a.rel_ld;
     const int np = a.rel_ld / 2;
     for (int i = tid; i < BQ * a.kh; i += NT) {
@@ -273,6 +292,37 @@ __global__ __launch_bounds__(NWV * 64) void attn_kernel(AttnArgs a) {
         sstore_tile(t);
       }
     __syncthreads();
+    if constexpr (BF) {
+      if (rel_tab) {
+        // P^T[entry][query] = R q^T for both tables: entry = 16 blk + 4 g + r, query = this lane's column; the
+        // reference's shifted gather (get_rel_pos) becomes a scatter: entry e of the h table is the bias of key
+        // row y + kh - 1 - e, where y is the query's own row
+        float4v ph[2], pw[2];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+          ph[blk] = float4v{0.f, 0.f, 0.f, 0.f};
+          pw[blk] = float4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int kk = 0; kk < HDK / KS; ++kk) {
+            ph[blk] = M_::mma(M_::lds(&Rs[(blk * 16 + qi) * LDK + kk * KS], lane), qf[kk], ph[blk]);
+            pw[blk] = M_::mma(M_::lds(&Rs[(32 + blk * 16 + qi) * LDK + kk * KS], lane), qf[kk], pw[blk]);
+          }
+        }
+        if (q_ok) {
+          const int y = iq / a.kw, x = iq - y * a.kw;
+#pragma unroll
+          for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int e = blk * 16 + 4 * g + r;
+              const int ch = y + a.kh - 1 - e, cw = x + a.kw - 1 - e;
+              if (ch >= 0 && ch < a.kh) relh_s[il * a.kh + ch] = ph[blk][r] * bsc;
+              if (cw >= 0 && cw < a.kw) relw_s[il * a.kw + cw] = pw[blk][r] * bsc;
+            }
+        }
+        __syncthreads();
+      }
+    }
   } else {
     if (kv_end > kt_begin) gload_tile(kt_begin);
   }
@@ -515,7 +565,13 @@ static void attn_launch_cfg(const AttnArgs& a_in, hipStream_t s) {
   size_t lds = sizeof(T) * (BKV * LDK + BKV * LDV) * (NRES > 0 ? NRES : 1);
   if (NRES > 0 && (a.Sk > NRES * BKV || a.Sq > BQ || a.kv_len || a.causal))
     throw std::runtime_error("attention: resident-key form needs Sk <= NRES * BKV and one query block");
-  if (a.rel_h || a.rel_p) lds += sizeof(float) * BQ * (a.kh + a.kw);
+  if (a.rel_h || a.rel_p || a.rel_tab_h) lds += sizeof(float) * BQ * (a.kh + a.kw);
+  if (a.rel_tab_h) {
+    if (NRES == 0 || sizeof(T) != 2 || 2 * a.kh - 1 > 32 || 2 * a.kw - 1 > 32 || a.rel_tab_ld % VEC ||
+        ((uintptr_t)a.rel_tab_h & 15) || ((uintptr_t)a.rel_tab_w & 15))
+      throw std::runtime_error("attention: rel-pos tables are taken by the bf16 resident-key form only (k <= 16)");
+    lds += sizeof(T) * 2 * 32 * LDK;
+  }
   if (lds > 160 * 1024) throw std::runtime_error("attention: LDS budget exceeded");
   static bool attr = false;
   if (!attr) {
@@ -573,6 +629,10 @@ static void attn_launch(const AttnArgs& a, hipStream_t s) {
     }
   }
   attn_launch_cfg<T, HD, 4, 0>(a, s);
+}
+
+bool attention_takes_rel_tables(int elem_bytes, int hd, int Sq, int Sk, int kh, int kw) {
+  return elem_bytes == 2 && hd == 80 && Sq == Sk && Sq > 192 && Sq <= 208 && kh <= 16 && kw <= 16;  // = attn_launch
 }
 
 template <typename T>

@@ -172,6 +172,12 @@ struct AttnArgs {
   const float* rel_p = nullptr;
   int64_t rel_hs = 0;  // head stride of P (elements)
   int rel_ld = 0;      // row stride of P = 2*Np
+  // or (3), SAM windows in the resident-key form only: the tables themselves, T [2*kh-1][hd] / [2*kw-1][hd] at row
+  // stride rel_tab_ld (2*k-1 <= 32); the kernel computes q . R^T with 12 MFMAs per wave from the query fragments it
+  // already holds and scatters it to the shifted layout -- no P buffer, no GEMM launch
+  const void* rel_tab_h = nullptr;
+  const void* rel_tab_w = nullptr;
+  int rel_tab_ld = 0;
   int o_f32 = 0;  // 1: O is f32 instead of T (decode step feeds the f32 GEMV)
   // set by the launcher: keys split over kv_splits workgroups per query block, partials merged afterwards
   int kv_splits = 1;
@@ -180,6 +186,9 @@ struct AttnArgs {
 };
 template <typename T>
 void launch_attention(const AttnArgs& a, hipStream_t s);
+// whether launch_attention<T> runs this (non-causal, full-length) shape in the resident-key form, which takes the
+// rel-pos TABLES (rel_tab_*) instead of a precomputed P
+bool attention_takes_rel_tables(int elem_bytes, int hd, int Sq, int Sk, int kh, int kw);
 
 // Decode-step attention for ONE new token per sequence, fused with RoPE and the KV-cache append:
 // qkv f32 [B,3*H*hd] (this step's projections) -> rotates q,k at pos[b], appends k,v to the cache,

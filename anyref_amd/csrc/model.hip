@@ -1150,7 +1150,12 @@ void Model<T>::sam_encoder(hipStream_t s, const float* images, int B, float* out
       norm(s, s_x_, D, L.ln1, s_hglob_, D, RT, D, 1e-6f, false);
       gemm(s, s_hglob_, D, L.qkv, s_qkv_, 3 * D, RT, ACT_NONE, false, nullptr, 0, tok2win_);
       launch_fill_rows_bias<T>(s_qkv_, 3 * D, pad_rows_, n_pad_rows_ * B, L.qkv.b, 3 * D, s);
-      rel_gemm(RW);
+      if (attention_takes_rel_tables((int)sizeof(T), hd, S2, S2, ws, ws)) {
+        // window bias straight from the tables inside the attention kernel (rows 0.. = rel_pos_h, Np.. = rel_pos_w)
+        a.rel_tab_h = L.rel.w; a.rel_tab_w = L.rel.w + (size_t)(L.rel.n / 2) * L.rel.k; a.rel_tab_ld = L.rel.k;
+      } else {
+        rel_gemm(RW);
+      }
       a.q_bs = a.k_bs = a.v_bs = (int64_t)S2 * 3 * D; a.o_bs = (int64_t)S2 * D;
       a.B = B * nW; a.Sq = S2; a.Sk = S2; a.kh = ws; a.kw = ws;
       launch_attention<T>(a, s);

@@ -73,6 +73,19 @@ int anyref_op_attention(int t, void* stream, const void* q, const void* k, const
   });
 }
 
+int anyref_op_attention_tab(void* stream, const void* q, const void* k, const void* v, void* o, int B, int H, int S,
+                            int hd, float scale, const void* tab_h, const void* tab_w, int tab_ld, int kh, int kw) {
+  OP_GUARD({
+    AttnArgs a;
+    a.Q = q; a.K = k; a.V = v; a.O = o;
+    a.q_bs = a.k_bs = a.v_bs = a.o_bs = (int64_t)S * H * hd;
+    a.q_rs = a.k_rs = a.v_rs = a.o_rs = H * hd; a.q_hs = a.k_hs = a.v_hs = a.o_hs = hd;
+    a.B = B; a.H = H; a.Sq = S; a.Sk = S; a.hd = hd; a.scale = scale;
+    a.rel_tab_h = tab_h; a.rel_tab_w = tab_w; a.rel_tab_ld = tab_ld; a.kh = kh; a.kw = kw;
+    launch_attention<bf16>(a, (hipStream_t)stream);
+  });
+}
+
 int anyref_op_rel_pos(int t, void* stream, const void* q, const float* tab_h, const float* tab_w, int B, int H,
                       int size, int hd, float* rel_h, float* rel_w) {
   OP_GUARD({

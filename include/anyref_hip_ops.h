@@ -55,6 +55,12 @@ int anyref_op_avs_counts(void* stream, const float* logits, const uint8_t* targe
  * std3 are HOST pointers. */
 int anyref_op_sam_preprocess(void* stream, const uint8_t* img, int h, int w, int S, const float* mean3,
                              const float* std3, float* out);
+/* bf16 window attention with the decomposed rel-pos bias computed inside the kernel from the tables
+ * (image_encoder.py:321-392 get_rel_pos / add_decomposed_rel_pos): tab_h bf16 [2*kh-1, hd], tab_w bf16 [2*kw-1, hd],
+ * rows at stride tab_ld elements; S = kh*kw tokens, [B,S,H,hd] operands.  Only the shapes the resident-key form
+ * takes (hd 80, 192 < S <= 208); others are refused. */
+int anyref_op_attention_tab(void* stream, const void* q, const void* k, const void* v, void* o, int B, int H, int S,
+                            int hd, float scale, const void* tab_h, const void* tab_w, int tab_ld, int kh, int kw);
 /* Sam.postprocess_masks on low [n,lh,lw] f32 */
 int anyref_op_postprocess(void* stream, const float* low, int n, int lh, int lw, int S, int rh, int rw, int H,
                           int W, float* out);

@@ -53,7 +53,7 @@ def rig_seg(cfg, sd, clip, sam, ids, sizes, hw, **kw):
 
 
 @pytest.mark.parametrize("mode", ["parity", "perf"])
-@pytest.mark.parametrize("window,sam_dim,sam_heads", [(14, 192, 3), (4, 160, 2)])
+@pytest.mark.parametrize("window,sam_dim,sam_heads", [(14, 192, 3), (4, 160, 2), (14, 240, 3)])  # last: hd 80, 196-token windows
 def test_generate_matches_oracle(mode, window, sam_dim, sam_heads):
     from anyref_amd.model import AnyRefForCausalLM
     cfg = config_tiny(window=window, sam_dim=sam_dim, sam_heads=sam_heads)

@@ -221,6 +221,38 @@ def test_sam_attention_rel_pos(lib, ty, B, H, size, hd):
     close(o, ref, 3e-2 if ty else 5e-5)
 
 
+@pytest.mark.parametrize("B,H", [(1, 1), (5, 3)])
+def test_sam_window_attention_bias_from_tables(lib, B, H):
+    """SAM-H windows (14 x 14, hd 80, bf16): the kernel computes q . R^T itself from the rel-pos tables and applies
+    the get_rel_pos shift as a scatter (image_encoder.py:321-392); refused for shapes outside that form."""
+    size, hd, ld = 14, 80, 128
+    g = torch.Generator().manual_seed(B * 7 + H)
+    S = size * size
+    q, k, v = (torch.randn(B, S, H, hd, generator=g) for _ in range(3))
+    th, tw = (rnd(torch.randn(2 * size - 1, hd, generator=g) * 0.3, 1) for _ in range(2))
+    idx = torch.arange(size)[:, None] - torch.arange(size)[None, :] + size - 1
+    qr = rnd(q, 1)
+    rq = qr.permute(0, 2, 1, 3).reshape(B, H, size, size, hd)
+    rel_h = torch.einsum("bnhwc,hkc->bnhwk", rq, th[idx]).reshape(B, H, S, size)
+    rel_w = torch.einsum("bnhwc,wkc->bnhwk", rq, tw[idx]).reshape(B, H, S, size)
+    scale = hd ** -0.5
+    ref = ref_attention(qr, rnd(k, 1), rnd(v, 1), scale, False, None, rel_h, rel_w, size)
+    tab = torch.zeros(2, 2 * size, ld)                      # padded rows / columns as the model packs them
+    tab[0, : 2 * size - 1, :hd], tab[1, : 2 * size - 1, :hd] = th, tw
+    tab = tab.bfloat16().cuda()
+    o = torch.empty(B, S, H, hd, device="cuda", dtype=torch.bfloat16)
+    check(lib, lib.anyref_op_attention_tab(None, P(dev(q, 1)), P(dev(k, 1)), P(dev(v, 1)), P(o), B, H, S, hd, scale,
+                                           P(tab[0]), P(tab[1]), ld, size, size))
+    close(o, ref, 3e-2)
+    # the same call against the precomputed-bias path of the same kernel: only the f32 summation order differs
+    o2 = torch.empty_like(o)
+    check(lib, lib.anyref_op_attention(1, None, P(dev(q, 1)), P(dev(k, 1)), P(dev(v, 1)), P(o2), B, H, S, S, hd, scale, 0,
+                                       None, P(rel_h.cuda().contiguous()), P(rel_w.cuda().contiguous()), size, size))
+    close(o, o2.float(), 1e-2)
+    assert lib.anyref_op_attention_tab(None, P(dev(q, 1)), P(dev(k, 1)), P(dev(v, 1)), P(o), B, H, 100, hd, scale,
+                                       P(tab[0]), P(tab[1]), ld, 10, 10) != 0      # not a resident-form shape
+
+
 @pytest.mark.parametrize("n,lh,S,rs,os_", [(2, 56, 224, (224, 224), (224, 224)), (3, 56, 224, (150, 224), (301, 437)),
                                            (1, 256, 1024, (683, 1024), (427, 640))])
 def test_postprocess(lib, n, lh, S, rs, os_):
