@@ -251,3 +251,41 @@ def test_decode_mfma_path_batch_gt4(mode):
             if o6[b, : len(ids[b]) + 8].cpu().tolist() == ref["output_ids"][0].tolist():
                 herr = (ex6["hidden"][b, :n].cpu() - ref["hidden"][0][:n]).abs().max().item()
                 assert herr < 0.15, f"row {b}: hidden err vs oracle {herr}"
+
+
+@pytest.mark.parametrize("mode", ["parity", "perf"])
+def test_generate_llama7b_shaped_layers_vs_oracle(mode):
+    """Two decoder layers at LLaMA-7B's real widths (4096 / 32 heads of 128 / MLP 11008; vocab 1000) behind the tiny
+    vision towers: prefill and the decode steps run the shapes the headline run uses -- 64x256 and split-K GEMM
+    tiles with the fused norm / SwiGLU epilogues, and the decode GEMVs over the padded weight rows (K = 4096 and the
+    16-byte-staged K = 11008) -- and every hidden state (prompt rows from prefill, new rows from decode) is held
+    against the CPU fp32 oracle."""
+    import dataclasses
+    from anyref_amd.config import LlmConfig
+    from anyref_amd.model import AnyRefForCausalLM
+    cfg = config_tiny()
+    cfg = dataclasses.replace(cfg, llm=LlmConfig(vocab=1000, dim=4096, heads=32, layers=2, mlp=11008, max_seq=512))
+    sd = synth_state_dict(cfg, seed=21, scale=0.02)
+    if mode == "perf":   # both sides on bf16-rounded weights (bench.py's convention)
+        sd = {k: (v.bfloat16().float() if v.is_floating_point() else v) for k, v in sd.items()}
+    clip, sam, ids = make_inputs(cfg, 1, seed=22, L=65)        # 65 ids + 255 image tokens = the S = 320 prompt
+    sizes, H, W = [(224, 224)], [224], [224]
+    rig_seg(cfg, sd, clip, sam, ids, sizes, (H, W))
+    with torch.no_grad():
+        ref = O.anyref_generate(sd, cfg, clip, ids, sam, sizes, H, W, max_new_tokens=6, eos=False)
+    m = AnyRefForCausalLM.from_state_dict(cfg, {k: v.cuda() for k, v in sd.items()}, mode=mode, max_batch=1, max_seg=4)
+    m.config.eos_token_id = None
+    (out_ids, masks, _), ex = m.generate(clip, ids[0][None], sam, sizes, H, W, max_new_tokens=6, _return_extras=True)
+    same = out_ids[0].cpu().tolist() == ref["output_ids"][0].tolist()
+    if mode == "parity":
+        assert same, "greedy ids differ"
+    n = ref["hidden"][0].shape[0]
+    assert n == 320 + 5
+    got, want = ex["hidden"][0, :n].cpu(), ref["hidden"][0]
+    scale = want.abs().max().item()
+    perr = (got[:320] - want[:320]).abs().max().item()
+    assert perr < (2e-4 if mode == "parity" else 0.05) * max(1.0, scale), f"prefill hidden err {perr} (scale {scale})"
+    if same:   # the decode rows are comparable only along the same token path
+        derr = (got[320:] - want[320:]).abs().max().item()
+        assert derr < (2e-4 if mode == "parity" else 0.05) * max(1.0, scale), f"decode hidden err {derr} (scale {scale})"
+        print(f"[{mode}] prefill / decode hidden max-abs-err {perr:.3e} / {derr:.3e} (scale {scale:.2f})")
