@@ -486,16 +486,17 @@ class AnyRefForCausalLM:
 
 
 def dice_loss(inputs, targets, num_masks, scale=1000, eps=1e-6):
-    """`dice_loss` (model/anyref.py:19-44)."""
+    """`dice_loss` (model/anyref.py:19-47): the live body adds 1 to numerator and denominator and divides by
+    `num_masks`; `scale` / `eps` are dead arguments there (the scaled variant is commented out, :38-42)."""
     inputs = inputs.sigmoid().flatten(1, 2)
     targets = targets.flatten(1, 2)
-    numerator = 2 * (inputs / scale * targets).sum(-1)
-    denominator = (inputs / scale).sum(-1) + (targets / scale).sum(-1)
-    loss = 1 - (numerator + eps) / (denominator + eps)
-    return loss.sum() / (num_masks + 1e-8)
+    numerator = 2 * (inputs * targets).sum(-1)
+    denominator = inputs.sum(-1) + targets.sum(-1)
+    loss = 1 - (numerator + 1) / (denominator + 1)
+    return loss.sum() / num_masks
 
 
 def sigmoid_ce_loss(inputs, targets, num_masks):
-    """`sigmoid_ce_loss` (model/anyref.py:47-68)."""
+    """`sigmoid_ce_loss` (model/anyref.py:51-68)."""
     loss = F.binary_cross_entropy_with_logits(inputs, targets, reduction="none")
     return loss.flatten(1, 2).mean(1).sum() / (num_masks + 1e-8)

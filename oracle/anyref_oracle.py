@@ -13,13 +13,20 @@ This is an independent restatement (plain torch CPU ops, fp32) of the arithmetic
     `LlamaForCausalLM` + `CLIPVisionModel` + upstream LLaVA v1.1 multimodal splice
     (call sites `model/anyref.py:341-354,704-716`).
 
-Pinning: the reference has no tests / golden vectors.  The SAM half of
-this file is pinned against outputs of the reference's own SAM `modeling` package run
-in the build container (`tests/golden/make_golden.py` -> `tests/golden/sam_*.npz`).
-The LLaMA / CLIP half is pinned against the HF transformers 5.15 stand-in
-(`tests/golden/llm_clip_*.npz`); the 4.31 behaviour underneath the missing `model/llava`
-package itself cannot be run here, so for that half **parity is unpinned** w.r.t. the
-reference and pinned only w.r.t. the stand-in.
+Pinning: the reference has no tests / golden vectors of its own, so every pin is
+an output of the reference's code RUN in the build container by a committed script:
+  * SAM half (`sam_image_encoder`, `dense_pe`, `two_way_transformer`, `mask_decoder_predict`,
+    `postprocess_masks`): `tests/golden/make_golden.py` -> `sam_*.npz` (small shapes) and
+    `sam_h_width.npz` (SAM-H's real width / head_dim / window at 1024^2, 4 blocks).
+  * Glue (`generate_tail`, `forward_tail`, `ref_features_*`, `text_hidden_fc`, the two losses):
+    `tests/golden/make_golden_glue.py` runs the reference's `model/anyref.py` (:19-68, :96-161,
+    :239-466, :647-822) on CANNED LLM outputs -> `glue_anyref.npz`.
+  * Metrics (`intersection_and_union`, `avs_*`): `tests/golden/make_golden_metrics.py` runs the
+    reference's `utils/utils.py` / `utils/pyutils.py` -> `metrics_ref.npz`.
+  * LLaMA / CLIP half (`clip_patch_tokens`, `llama_*`, `greedy_generate`): the reference's
+    `model/llava/**` is git-ignored and absent; pinned against the HF transformers 5.15 stand-in
+    only (`llm_clip_hf.npz`) -- w.r.t. the reference this half is **parity unpinned**.  So is
+    `splice_embeddings` / `splice_ref_rows` (the llava layer's splice, inferred from call sites).
 
 All functions take a flat dict `w` of fp32 tensors keyed by the reference's
 state_dict names (SURVEY.md §8b "Weight names").
@@ -419,7 +426,7 @@ def mask_decoder_predict(w: W, cfg, image_embedding: torch.Tensor, image_pe: tor
     hyper = torch.stack([_mlp3(w, f"{p}output_hypernetworks_mlps.{i}.", mask_tok[:, i])
                          for i in range(s.num_mask_tokens)], 1)
     b, c2, h2, w2 = x.shape
-    masks = (hyper @ x.view(b, c2, h2 * w2)).view(b, -1, h2, w2)
+    masks = (hyper @ x.view(b, c2, h2 * w2)).view(b, s.num_mask_tokens, h2, w2)   # b may be 0 (a row without [SEG])
     iou = _mlp3(w, p + "iou_prediction_head.", iou_tok)
     return masks, iou
 
@@ -454,113 +461,182 @@ def _is_seg(cfg, ids: torch.Tensor) -> torch.Tensor:
     return (ids >= lo) & (ids <= hi)
 
 
+def pool_ref_tokens(f: torch.Tensor, n_out: int = 4) -> torch.Tensor:
+    """[b, 256, c] -> mean over groups of 16 -> [b, 16, c] -> (if 16 != IMG_REF_NUM) mean over groups of
+    IMG_REF_NUM -> [b, IMG_REF_NUM, c]   (anyref.py:335-338, :697-700)."""
+    b, ll, c = f.shape
+    f = f.reshape(b, ll // 16, 16, c).mean(dim=2)
+    if f.shape[1] != n_out:
+        f = f.reshape(b, n_out, n_out, c).mean(dim=2)
+    return f
+
+
+def ref_features_generate(encode, ref_images, bs: int, n_out: int = 4):
+    """What `generate` hands to the (absent) llava layer as `ref_images=` (anyref.py:681-702).
+    `encode(x [n,3,S,S]) -> [n,256,H]` stands for `self.encode_images`.  NOTE the asymmetry, kept as the
+    reference has it: LIST items go down UNPOOLED ([256,H] each, :691-692; 1-D RoI coordinates pass
+    through, :688-689), a TENSOR batch is pooled 256 -> 16 -> IMG_REF_NUM (:695-700)."""
+    if ref_images is None:
+        return None
+    if isinstance(ref_images, list):
+        out = []
+        for r in ref_images:
+            if r is None:
+                out.append(None)
+            elif r.dim() == 1:
+                out.append(r)
+            else:
+                out.append(encode(r[None])[0])
+        return out
+    if ref_images.shape[0] == bs and ref_images.ndim == 4:
+        return pool_ref_tokens(encode(ref_images), n_out)
+    raise NotImplementedError
+
+
+def ref_features_forward(encode, ref_images, n_out: int = 4):
+    """The teacher-forced twin (anyref.py:319-339): a list only, every image item POOLED to IMG_REF_NUM rows."""
+    if ref_images is None:
+        return None
+    out = []
+    for r in ref_images:
+        if r is None:
+            out.append(None)
+        elif r.dim() == 1:
+            out.append(r)
+        else:
+            out.append(pool_ref_tokens(encode(r[None]), n_out)[0])
+    return out
+
+
+def splice_ref_rows(f: Optional[torch.Tensor], n_slots: int):
+    """The absent llava layer receives [256,H] (generate, list form) or [IMG_REF_NUM,H] rows for the IMG_REF_NUM
+    `<img_ref>` placeholders of a prompt (utils/coco20i.py:319 "put 4 * <ref_img>").  Its source is not in the
+    reference; this build's reading (INFERRED, unpinned): unpooled features are pooled exactly as the forward
+    path pools them (:335-338) before the 1:1 replacement."""
+    if f is None or f.shape[0] == n_slots:
+        return f
+    return pool_ref_tokens(f[None], n_slots)[0]
+
+
+def generate_tail(w: W, cfg, output_ids: List[torch.Tensor], prompt_lens: Sequence[int],
+                  hiddens: List[torch.Tensor], attns: Optional[List[Optional[torch.Tensor]]],
+                  sam_images, sam_resized_sizes, height, width):
+    """Everything `generate` does AFTER `super().generate` returns (anyref.py:718-822), for per-sample LLM
+    outputs: `output_ids[b]` [L_b+T_b], `hiddens[b]` = `outputs.hidden_states[-1][b]` [L_b+T_b-1+255, H],
+    `attns[b]` = `outputs.attentions[-1][b]` [heads,S,S] (or its head mean [S,S]).
+
+    Pinned by `tests/golden/glue_*.npz`: the reference's own lines run on canned LLM outputs.
+
+    Batch convention of this build: every row is a batch of one.  For a batch of one the reference rephrases
+    the FIRST [SEG] only (`for i in range(bs)` indexes the flattened [SEG] list, :739-741,:768-769); in a real
+    batch the reference pairs the i-th [SEG] of the flattened list with sample i's states, which coincides
+    with this whenever every row holds exactly one [SEG]."""
+    B = len(output_ids)
+    seg_hidden, seg_batch = [], []
+    for b in range(B):
+        ids, hidden = output_ids[b], hiddens[b]
+        pos = torch.where(_is_seg(cfg, ids[1:]))[0]                       # :723-726
+        for j, p_ in enumerate(pos.tolist()):
+            h = hidden[p_ + 255].clone()                                   # :758
+            if cfg.rephrase_weight > 0 and j == 0:
+                a = attns[b]
+                if a.dim() == 3:
+                    a = a.mean(0)                                          # :748
+                s0, e0 = prompt_lens[b] - 1 + 255, p_ + 255                # :745, :741
+                a = a[e0, s0:e0]
+                a = a / a.sum()                                            # :749-750
+                h = h + (hidden[s0:e0] * a[:, None]).sum(0) * cfg.rephrase_weight   # :754, :769
+            seg_hidden.append(h)
+            seg_batch.append(b)
+    if not seg_hidden:                                                     # :729-730
+        return dict(pred_masks=None, low_res=None, pred_embeddings=None)
+    pred = text_hidden_fc(w, torch.stack(seg_hidden))                      # :770
+    img_emb = sam_image_encoder(w, cfg, sam_images)                        # :793
+    seg_batch_t = torch.tensor(seg_batch)
+    masks, lows = [], []
+    for b in range(B):                                                     # :797-819
+        pe = pred[seg_batch_t == b]
+        m, low = sam_decode(w, cfg, img_emb[b:b + 1], pe, sam_resized_sizes[b], (height[b], width[b]))
+        masks.append(m); lows.append(low)
+    return dict(pred_masks=masks, low_res=lows, pred_embeddings=pred, image_embeddings=img_emb)
+
+
 def anyref_generate(w: W, cfg, clip_images, input_ids: List[torch.Tensor], sam_images,
                     sam_resized_sizes, height, width, audio_embeds=None, ref_feats=None,
                     max_new_tokens: int = 128, use_cache: bool = True, eos: bool = True):
     """Restatement of AnyRefForCausalLM.generate for a list of per-sample prompts (each run
     exactly as the reference runs a batch of one).  `audio_embeds[b]`: ImageBind embedding
     [3,1024] or None (the encoder itself is outside the path).
+    `ref_feats[b]`: what `ref_features_generate` returns for row b (rows [256,H] or [IMG_REF_NUM,H]) or None.
 
     Returns dict(output_ids=list[Tensor], pred_masks=list[Tensor[n,H,W]] or None, low_res=...,
     hidden=list, pred_embeddings=list)."""
     B = len(input_ids)
     img_feats = encode_images(w, cfg, clip_images)
-    out_ids, seg_hidden, seg_batch = [], [], []
-    hiddens = []
+    out_ids, hiddens, attns = [], [], []
     for b in range(B):
         af = None
         if audio_embeds is not None and audio_embeds[b] is not None:
-            af = _lin(audio_embeds[b], w, "model.audio_projector")
+            af = _lin(audio_embeds[b], w, "model.audio_projector")          # :673
         rf = None
         if ref_feats is not None and ref_feats[b] is not None:
-            rf = ref_feats[b]
+            rf = splice_ref_rows(ref_feats[b], int((input_ids[b] == IMG_REF_INDEX).sum()))
         emb = splice_embeddings(w, cfg, input_ids[b], img_feats[b], af, rf)
         new_ids, hidden, attn = greedy_generate(
             w, cfg, emb, max_new_tokens, cfg.eos_token_id if eos else None, use_cache,
             want_attn=cfg.rephrase_weight > 0)
-        ids = torch.cat([input_ids[b], torch.tensor(new_ids, dtype=torch.long)])
-        out_ids.append(ids)
+        out_ids.append(torch.cat([input_ids[b], torch.tensor(new_ids, dtype=torch.long)]))
         hiddens.append(hidden)
-        pos = torch.where(_is_seg(cfg, ids[1:]))[0]
-        L = input_ids[b].shape[0]
-        for j, p_ in enumerate(pos.tolist()):
-            h = hidden[p_ + 255].clone()
-            if cfg.rephrase_weight > 0 and j == 0:
-                # anyref.py:735-755,767-769: only the first [SEG] of sample i gets rephrased
-                s0, e0 = L - 1 + 255, p_ + 255
-                a = attn[e0, s0:e0]
-                a = a / a.sum()
-                h = h + (hidden[s0:e0] * a[:, None]).sum(0) * cfg.rephrase_weight
-            seg_hidden.append(h)
-            seg_batch.append(b)
-    if not seg_hidden:
-        return dict(output_ids=out_ids, pred_masks=None, low_res=None, hidden=hiddens, pred_embeddings=None)
-    pred = text_hidden_fc(w, torch.stack(seg_hidden))
-    img_emb = sam_image_encoder(w, cfg, sam_images)
-    seg_batch_t = torch.tensor(seg_batch)
-    masks, lows = [], []
-    for b in range(B):
-        pe = pred[seg_batch_t == b]
-        m, low = sam_decode(w, cfg, img_emb[b:b + 1], pe, sam_resized_sizes[b], (height[b], width[b]))
-        masks.append(m); lows.append(low)
-    return dict(output_ids=out_ids, pred_masks=masks, low_res=lows, hidden=hiddens,
-                pred_embeddings=pred, image_embeddings=img_emb)
+        attns.append(attn)
+    tail = generate_tail(w, cfg, out_ids, [len(r) for r in input_ids], hiddens, attns, sam_images,
+                         sam_resized_sizes, height, width)
+    return dict(output_ids=out_ids, hidden=hiddens, **tail)
 
 
 def dice_loss(inputs, targets, num_masks, scale=1000, eps=1e-6):
-    """anyref.py:19-44."""
+    """anyref.py:19-47 -- the LIVE body (:35-37,:43-47); `scale` and `eps` are dead arguments there (the
+    scaled form is commented out, :38-42)."""
     inputs = inputs.sigmoid().flatten(1, 2)
     targets = targets.flatten(1, 2)
-    num = 2 * (inputs / scale * targets).sum(-1)
-    den = (inputs / scale).sum(-1) + (targets / scale).sum(-1)
-    loss = 1 - (num + eps) / (den + eps)
-    return loss.sum() / (num_masks + 1e-8)
+    num = 2 * (inputs * targets).sum(-1)
+    den = inputs.sum(-1) + targets.sum(-1)
+    loss = 1 - (num + 1) / (den + 1)
+    return loss.sum() / num_masks
 
 
 def sigmoid_ce_loss(inputs, targets, num_masks):
-    """anyref.py:47-68."""
+    """anyref.py:51-68."""
     loss = F.binary_cross_entropy_with_logits(inputs, targets, reduction="none")
     return loss.flatten(1, 2).mean(1).sum() / (num_masks + 1e-8)
 
 
-def anyref_forward(w: W, cfg, clip_images, sam_images, input_ids: List[torch.Tensor],
-                   labels: List[torch.Tensor], sam_resized_sizes, gt_masks, height, width,
-                   audio_embeds=None, ce_loss_weight=1.0, dice_loss_weight=0.5, bce_loss_weight=2.0):
-    """Teacher-forced `model_forward_new` (anyref.py:239-466) for unpadded per-sample prompts."""
+def forward_tail(w: W, cfg, input_ids: List[torch.Tensor], labels: List[torch.Tensor],
+                 hiddens: List[torch.Tensor], attns: Optional[List[Optional[torch.Tensor]]], lm_loss,
+                 sam_images, sam_resized_sizes, gt_masks, height, width,
+                 dice_loss_weight=0.5, bce_loss_weight=2.0):
+    """Everything `model_forward_new` does around `super().forward` (anyref.py:273-282 [SEG] search with the
+    `pos - 1 + 255` offset, :356-466 hand-off, rephrase, mask decode, BCE + Dice), for per-sample LLM outputs
+    (`hiddens[b]` = `output.hidden_states[-1][b]`, `attns[b]` = `output.attentions[-1][b]`, `lm_loss` =
+    `output.loss`).  Pinned by `tests/golden/glue_*.npz`.  Same batch-of-one convention as `generate_tail`."""
     B = len(input_ids)
-    img_feats = encode_images(w, cfg, clip_images)
     seg_hidden, seg_batch = [], []
-    lm_num, lm_den = 0.0, 0
-    hiddens = []
     for b in range(B):
-        af = None
-        if audio_embeds is not None and audio_embeds[b] is not None:
-            af = _lin(audio_embeds[b], w, "model.audio_projector")
-        emb = splice_embeddings(w, cfg, input_ids[b], img_feats[b], af, None)
-        hidden, attn = llama_layers(w, cfg, emb, cfg.rephrase_weight > 0)
-        hiddens.append(hidden)
-        # HF causal-LM loss with the image span labelled IGNORE (LLaVA splice semantics)
-        ids = input_ids[b]
-        ip = int(torch.where(ids == IMAGE_TOKEN_INDEX)[0][0])
-        lab = torch.cat([labels[b][:ip], torch.full((256,), -100, dtype=torch.long), labels[b][ip + 1:]])
-        logits = F.linear(hidden, w["lm_head.weight"])
-        valid = lab[1:] != -100
-        if valid.any():
-            lm_num = lm_num + F.cross_entropy(logits[:-1][valid], lab[1:][valid], reduction="sum")
-            lm_den += int(valid.sum())
-        pos = torch.where(_is_seg(cfg, ids))[0]
+        hidden = hiddens[b]
+        pos = torch.where(_is_seg(cfg, input_ids[b]))[0]                  # :273-276
         for j, p_ in enumerate(pos.tolist()):
-            e0 = p_ - 1 + 255
+            e0 = p_ - 1 + 255                                              # :282
             h = hidden[e0].clone()
             if cfg.rephrase_weight > 0 and j == 0:
-                s0 = int(torch.where(labels[b] > 0)[0][0]) - 1 + 255
-                a = attn.mean(0)[e0, s0:e0]
+                s0 = int(torch.where(labels[b] > 0)[0][0]) - 1 + 255       # :378
+                a = attns[b]
+                if a.dim() == 3:
+                    a = a.mean(0)
+                a = a[e0, s0:e0]
                 a = a / a.sum()
                 h = h + (hidden[s0:e0] * a[:, None]).sum(0) * cfg.rephrase_weight
             seg_hidden.append(h); seg_batch.append(b)
-    lm_loss = lm_num / max(lm_den, 1)
-    if not seg_hidden:
-        return dict(loss=lm_loss, lm_loss=lm_loss, hidden=hiddens)
+    if not seg_hidden:                                                     # :356-365
+        return dict(loss=lm_loss, lm_loss=lm_loss)
     pred = text_hidden_fc(w, torch.stack(seg_hidden))
     img_emb = sam_image_encoder(w, cfg, sam_images)
     seg_batch_t = torch.tensor(seg_batch)
@@ -571,7 +647,7 @@ def anyref_forward(w: W, cfg, clip_images, sam_images, input_ids: List[torch.Ten
         m, _ = sam_decode(w, cfg, img_emb[b:b + 1], pred[seg_batch_t == b], sam_resized_sizes[b],
                           (height[b], width[b]))
         masks.append(m)
-        if gt_masks is not None:
+        if gt_masks is not None:                                           # :432-446
             gt = gt_masks[b].to(m)
             pm = m
             if pm.shape[-2:] != gt.shape[-2:]:
@@ -579,11 +655,43 @@ def anyref_forward(w: W, cfg, clip_images, sam_images, input_ids: List[torch.Ten
             ce = ce + sigmoid_ce_loss(pm, gt, gt.shape[0]) * gt.shape[0]
             dice = dice + dice_loss(pm, gt, gt.shape[0]) * gt.shape[0]
             nm += gt.shape[0]
-    out = dict(lm_loss=lm_loss, pred_masks=masks, hidden=hiddens, pred_embeddings=pred)
-    if gt_masks is not None:
+    out = dict(lm_loss=lm_loss, pred_masks=masks, pred_embeddings=pred)
+    if gt_masks is not None:                                               # :448-466
         ce = bce_loss_weight * ce / (nm + 1e-8)
         dice = dice_loss_weight * dice / (nm + 1e-8)
         out.update(ce_loss=ce, dice_loss=dice, mask_loss=ce + dice, loss=lm_loss + ce + dice)
+    return out
+
+
+def anyref_forward(w: W, cfg, clip_images, sam_images, input_ids: List[torch.Tensor],
+                   labels: List[torch.Tensor], sam_resized_sizes, gt_masks, height, width,
+                   audio_embeds=None, ce_loss_weight=1.0, dice_loss_weight=0.5, bce_loss_weight=2.0):
+    """Teacher-forced `model_forward_new` (anyref.py:239-466) for unpadded per-sample prompts."""
+    B = len(input_ids)
+    img_feats = encode_images(w, cfg, clip_images)
+    lm_num, lm_den = 0.0, 0
+    hiddens, attns = [], []
+    for b in range(B):
+        af = None
+        if audio_embeds is not None and audio_embeds[b] is not None:
+            af = _lin(audio_embeds[b], w, "model.audio_projector")
+        emb = splice_embeddings(w, cfg, input_ids[b], img_feats[b], af, None)
+        hidden, attn = llama_layers(w, cfg, emb, cfg.rephrase_weight > 0)
+        hiddens.append(hidden)
+        attns.append(attn)
+        # HF causal-LM loss with the image span labelled IGNORE (LLaVA splice semantics)
+        ids = input_ids[b]
+        ip = int(torch.where(ids == IMAGE_TOKEN_INDEX)[0][0])
+        lab = torch.cat([labels[b][:ip], torch.full((256,), -100, dtype=torch.long), labels[b][ip + 1:]])
+        logits = F.linear(hidden, w["lm_head.weight"])
+        valid = lab[1:] != -100
+        if valid.any():
+            lm_num = lm_num + F.cross_entropy(logits[:-1][valid], lab[1:][valid], reduction="sum")
+            lm_den += int(valid.sum())
+    lm_loss = lm_num / max(lm_den, 1)
+    out = forward_tail(w, cfg, input_ids, labels, hiddens, attns, lm_loss, sam_images, sam_resized_sizes, gt_masks,
+                       height, width, dice_loss_weight, bce_loss_weight)
+    out["hidden"] = hiddens
     return out
 
 

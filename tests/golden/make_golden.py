@@ -124,6 +124,42 @@ def make_sam(name, cfg, seed):
     print(name, "emb", tuple(emb.shape), "low", tuple(low.shape), "post_b", tuple(post_b.shape))
 
 
+def sam_h_width_cfg():
+    """SAM-H's real shapes (build_sam.py:15-22: 1024^2 image, width 1280, 16 heads of 80, window 14) cut to 4
+    blocks (3 windowed + 1 global) so the reference runs in seconds."""
+    c = AnyRefConfig(clip=ClipConfig(image_size=224, patch=14, dim=64, heads=2, layers=2, mlp=128),
+                     llm=LlmConfig(vocab=200, dim=64, heads=2, layers=1, mlp=96, max_seq=512))
+    c.sam = SamConfig(img_size=1024, patch=16, dim=1280, depth=4, heads=16, window=14, global_idx=(3,))
+    return c
+
+
+def sam_h_width_inputs(seed):
+    return torch.randn(1, 3, 1024, 1024, generator=torch.Generator().manual_seed(seed + 1))
+
+
+def make_sam_h_width(seed=11):
+    sys.path.insert(0, REF_SAM)
+    import modeling as ref
+    from functools import partial
+    cfg = sam_h_width_cfg()
+    s = cfg.sam
+    sd = synth_state_dict(cfg, seed=seed, scale=0.02)
+    enc = ref.ImageEncoderViT(
+        depth=s.depth, embed_dim=s.dim, img_size=s.img_size, mlp_ratio=s.mlp_ratio,
+        norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), num_heads=s.heads, patch_size=s.patch,
+        qkv_bias=True, use_rel_pos=True, global_attn_indexes=list(s.global_idx),
+        window_size=s.window, out_chans=s.out_chans).eval()
+    pre = SAM_PREFIX + "image_encoder."
+    enc.load_state_dict({k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}, strict=True)
+    img = sam_h_width_inputs(seed)
+    with torch.no_grad():
+        emb = enc(img)
+    np.savez_compressed(os.path.join(HERE, "sam_h_width.npz"), seed=seed, wsum=checksum(sd, pre),
+                        insum=np.float64(img.double().abs().sum()), emb=emb.numpy()[:, ::4, ::2, ::2],
+                        absmax=np.float64(emb.abs().max()))
+    print("sam_h_width: emb", tuple(emb.shape), "absmax", float(emb.abs().max()))
+
+
 def make_llm_clip(seed=7):
     from transformers import LlamaConfig, LlamaForCausalLM, CLIPVisionConfig, CLIPVisionModel
     cfg = llm_clip_cfg()
@@ -172,3 +208,4 @@ if __name__ == "__main__":
     for i, (name, cfg) in enumerate(golden_cfgs().items()):
         make_sam(name, cfg, seed=11 + i)
     make_llm_clip()
+    make_sam_h_width()

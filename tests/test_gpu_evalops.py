@@ -137,3 +137,22 @@ def test_avs_edge_cases():
         mask_iou(z.cuda(), gt0[:, :4].cuda())
     with pytest.raises(RuntimeError):
         mask_iou(z, gt0)                              # host logits: no CPU fallback
+
+
+@pytest.mark.parametrize("name", ["m_small", "m_ragged", "m_empty_gt"])
+def test_metrics_against_reference_fixtures(name):
+    """The HIP metric kernels against numbers the reference's own utils/utils.py / utils/pyutils.py produced
+    (tests/golden/make_golden_metrics.py, run in the build container)."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_golden_metrics as gm
+    from anyref_amd.evalops import intersection_and_union, mask_iou, eval_fmeasure
+    fx = np.load(os.path.join(ROOT, "tests", "golden", "metrics_ref.npz"))
+    logits, gt, lab = gm.metric_inputs(name)
+    got = intersection_and_union(logits.cuda(), lab.cuda())
+    assert np.array_equal(torch.stack([g.cpu() for g in got]).numpy(), fx[name + ".iu"])
+    per = intersection_and_union(logits.cuda(), lab.cuda(), per_mask=True)
+    for k in range(logits.shape[0]):
+        assert np.array_equal(torch.stack([p[k].cpu() for p in per]).numpy(), fx[f"{name}.iu{k}"])
+    assert float(mask_iou(logits.cuda(), gt.cuda())) == float(fx[name + ".miou"])
+    assert eval_fmeasure(logits.cuda(), gt.float().cuda(), None) == float(fx[name + ".fscore"])

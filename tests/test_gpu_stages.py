@@ -102,20 +102,18 @@ def test_sam_h_shaped_encoder_vs_oracle(mode):
     14 padded 64 -> 70; image_encoder.py:17-125) cut to 4 blocks (3 windowed + 1 global) so the CPU oracle takes
     seconds: every big-shape path of the perf build -- 256^2 / 256x320 / 128x160 / 128^2 GEMM tiles, the row-map
     window scatter, the resident-key window attention with in-kernel rel-pos tables, 8-wave global attention --
-    against the fp32 restatement."""
-    import dataclasses
-    from anyref_amd.config import SamConfig, config_tiny
-    cfg = config_tiny()
-    cfg = dataclasses.replace(cfg, sam=SamConfig(img_size=1024, patch=16, dim=1280, depth=4, heads=16, window=14,
-                                                 global_idx=(3,)))
-    sd = synth_state_dict(cfg, seed=11, scale=0.02)
-    g = torch.Generator().manual_seed(12)
-    img = torch.randn(1, 3, 1024, 1024, generator=g)
-    if mode == "perf":   # both sides on the bf16-rounded weights (bench.py's convention): what is compared is the arithmetic
-        sd = {k: (v.bfloat16().float() if v.is_floating_point() else v) for k, v in sd.items()}
+    against the fp32 restatement AND against the output of the reference's own `ImageEncoderViT` at these shapes
+    (tests/golden/sam_h_width.npz)."""
+    cfg = mg.sam_h_width_cfg()
+    fx = np.load(os.path.join(HERE, "golden", "sam_h_width.npz"))
+    seed = int(fx["seed"])
+    sd = synth_state_dict(cfg, seed=seed, scale=0.02)          # synth weights are bf16-representable already
+    img = mg.sam_h_width_inputs(seed)
     with torch.no_grad():
         emb_ref = O.sam_image_encoder(sd, cfg, img)
     m = build(cfg, sd, mode, max_batch=1, max_seg=2)
     emb = m.sam_encode(img)
     assert emb.shape == emb_ref.shape == (1, 256, 64, 64)
-    close(emb, emb_ref, TOL[mode], "SAM-H-shaped image encoder vs oracle")
+    e1 = close(emb, emb_ref, TOL[mode], "SAM-H-shaped image encoder vs oracle")
+    e2 = close(emb[:, ::4, ::2, ::2], fx["emb"], TOL[mode], "SAM-H-shaped image encoder vs reference golden")
+    print(f"[{mode}] SAM-H-width encoder max-abs-err vs oracle {e1:.3e}, vs reference {e2:.3e} (range {float(fx['absmax']):.2f})")

@@ -100,3 +100,125 @@ def test_generate_cached_equals_uncached_tiny():
     assert a["pred_masks"] is not None and a["pred_masks"][0].shape[-2:] == (224, 224)
     assert torch.equal(a["output_ids"][0], b["output_ids"][0])
     _close(a["pred_masks"][0], b["pred_masks"][0].numpy(), 1e-4)
+
+
+# ------------------------------------------------------------------------------------------------
+# Glue: the reference's own `model/anyref.py` run on canned LLM outputs (tests/golden/make_golden_glue.py)
+# ------------------------------------------------------------------------------------------------
+import make_golden_glue as gg  # noqa: E402  (case tables + seeded inputs; touches /root/reference only in main())
+
+GLUE = np.load(os.path.join(HERE, "golden", "glue_anyref.npz"))
+
+
+def _glue_setup(c, seg_list=False):
+    cfg = gg.glue_cfg()
+    cfg.rephrase_weight = c["rephrase"]
+    cfg.seg_token_idx = gg.SEG_LIST if seg_list else gg.SEG
+    return cfg, synth_state_dict(cfg, seed=gg.SEED, scale=0.05)
+
+
+@pytest.mark.parametrize("name", list(gg.GEN_CASES))
+def test_generate_tail_against_reference(name):
+    """anyref.py:718-822 on canned `sequences` / `hidden_states[-1]` / `attentions[-1]`."""
+    x = gg.case_inputs(name)
+    c = x["c"]
+    cfg, w = _glue_setup(c, c.get("seg_list", False))
+    bs = c["bs"]
+    with torch.no_grad():
+        r = O.generate_tail(w, cfg, [x["seq"][b] for b in range(bs)], [c["L"]] * bs, [x["hidden"][b] for b in range(bs)],
+                            [x["attn"][b] for b in range(bs)], x["sam"], c["sizes"], [h for h, _ in c["hw"]],
+                            [w_ for _, w_ in c["hw"]])
+    if int(GLUE[name + ".masks_none"]):
+        assert r["pred_masks"] is None and int(GLUE[name + ".arity"]) == 3     # (ids, None, (None,)*3), :730
+        return
+    assert int(GLUE[name + ".arity"]) == 2                                     # the success path returns 2, :822
+    for b in range(bs):
+        assert list(r["pred_masks"][b].shape) == GLUE[f"{name}.shape{b}"].tolist()
+        if r["pred_masks"][b].shape[0]:
+            _close(r["pred_masks"][b][:, ::3, ::3], GLUE[f"{name}.mask{b}"], 3e-5)
+
+
+@pytest.mark.parametrize("name", list(gg.FWD_CASES))
+def test_forward_tail_against_reference(name):
+    """anyref.py:273-282,356-466 (hand-off at pos-1+255, rephrase, mask decode, BCE + Dice) on canned LLM outputs."""
+    x = gg.case_inputs(name)
+    c = x["c"]
+    cfg, w = _glue_setup(c)
+    bs = c["bs"]
+    with torch.no_grad():
+        r = O.forward_tail(w, cfg, [x["seq"][b] for b in range(bs)], [x["labels"][b] for b in range(bs)],
+                           [x["hidden"][b] for b in range(bs)], [x["attn"][b] for b in range(bs)], x["lm_loss"], x["sam"],
+                           c["sizes"], x["gt"], [h for h, _ in c["hw"]], [w_ for _, w_ in c["hw"]])
+    keys = GLUE[name + ".keys"].tolist()
+    assert sorted(k for k in r if k in ("loss", "lm_loss", "ce_loss", "dice_loss", "mask_loss")) == keys
+    for k in keys:
+        assert abs(float(r[k]) - float(GLUE[f"{name}.{k}"])) < 2e-5 * max(1.0, abs(float(GLUE[f"{name}.{k}"]))), k
+
+
+def test_handdown_and_losses_against_reference():
+    """What the glue hands to the llava layer for audio / reference images (anyref.py:303-339, :663-702) and the
+    two mask losses (:19-68)."""
+    cfg, w = _glue_setup(dict(rephrase=0.0))
+    hd = gg.handdown_inputs()
+    proj = lambda e: torch.nn.functional.linear(e, w["model.audio_projector.weight"], w["model.audio_projector.bias"])
+    with torch.no_grad():
+        _close(proj(hd["audio_emb"])[0], GLUE["hand.gen_list.audio0"], 2e-5)
+        _close(proj(hd["audio_emb"]), GLUE["hand.gen_tensor.audio"], 2e-5)
+        _close(proj(hd["audio_emb2"])[0], GLUE["hand.fwd_list.audio0"], 2e-5)
+        lst = O.ref_features_generate(gg.encode_stub, [hd["ref_a"]], 1)
+        assert lst[0].shape == (256, gg.H_LLM)                  # list items go down UNPOOLED in generate (:691-692)
+        _close(lst[0], GLUE["hand.gen_list.ref0"], 2e-5)
+        roi = O.ref_features_generate(gg.encode_stub, [hd["roi"]], 1)
+        assert np.array_equal(roi[0].numpy(), GLUE["hand.gen_list.roi0"])
+        ten = O.ref_features_generate(gg.encode_stub, hd["ref_a"][None], 1)
+        assert ten.shape == (1, gg.IMG_REF_NUM, gg.H_LLM)       # tensor batches are pooled 256 -> 16 -> 4 (:695-700)
+        _close(ten, GLUE["hand.gen_tensor.ref"], 2e-5)
+        fwd = O.ref_features_forward(gg.encode_stub, [hd["ref_b"]])
+        _close(fwd[0], GLUE["hand.fwd_list.ref0"], 2e-5)
+        # the llava-layer reading this build takes for unpooled rows equals the forward path's pooling
+        _close(O.splice_ref_rows(lst[0], gg.IMG_REF_NUM), GLUE["hand.gen_tensor.ref"][0], 2e-5)
+    g = torch.Generator().manual_seed(gg.SEED + 9)
+    lg = torch.randn(3, 40, 50, generator=g) * 3
+    tg = (torch.rand(3, 40, 50, generator=g) > 0.6).float()
+    assert abs(float(O.dice_loss(lg, tg, 3)) - float(GLUE["loss.dice"])) < 1e-6
+    assert abs(float(O.sigmoid_ce_loss(lg, tg, 3)) - float(GLUE["loss.bce"])) < 1e-6
+    from anyref_amd.model import dice_loss, sigmoid_ce_loss     # the mirror's copies of the two formulas
+    assert abs(float(dice_loss(lg, tg, 3)) - float(GLUE["loss.dice"])) < 1e-6
+    assert abs(float(sigmoid_ce_loss(lg, tg, 3)) - float(GLUE["loss.bce"])) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------------
+# Metrics: the reference's utils/utils.py + utils/pyutils.py run here (tests/golden/make_golden_metrics.py)
+# ------------------------------------------------------------------------------------------------
+import make_golden_metrics as gm  # noqa: E402
+
+METRICS = np.load(os.path.join(HERE, "golden", "metrics_ref.npz"))
+
+
+@pytest.mark.parametrize("name", list(gm.CASES))
+def test_metric_restatements_against_reference(name):
+    logits, gt, lab = gm.metric_inputs(name)
+    i, u, t = O.eval_mask_counts(logits, lab)                                      # utils/utils.py:79-91
+    assert np.array_equal(torch.stack([i, u, t]).numpy(), METRICS[name + ".iu"])
+    for k in range(logits.shape[0]):
+        i, u, t = O.eval_mask_counts(logits[k], lab[k])
+        assert np.array_equal(torch.stack([i, u, t]).numpy(), METRICS[f"{name}.iu{k}"])
+    assert float(O.avs_mask_iou(logits, gt)) == float(METRICS[name + ".miou"])      # pyutils.py:163-190
+    assert O.avs_fmeasure(logits, gt.float()) == float(METRICS[name + ".fscore"])   # pyutils.py:193-220
+    pr, rc = O.avs_pr_curve(torch.sigmoid(logits[0]), gt[0].float(), 255)           # pyutils.py:223-236
+    assert np.array_equal(pr.numpy(), METRICS[name + ".prec0"]) and np.array_equal(rc.numpy(), METRICS[name + ".recall0"])
+
+
+def test_sam_h_width_encoder_against_reference():
+    """The oracle's image encoder at SAM-H's real shapes (1024^2, width 1280, heads of 80, 14-windows padded 64 -> 70)
+    against the reference's `ImageEncoderViT` run at those shapes (4 blocks)."""
+    cfg = mg.sam_h_width_cfg()
+    fx = np.load(os.path.join(HERE, "golden", "sam_h_width.npz"))
+    seed = int(fx["seed"])
+    w = synth_state_dict(cfg, seed=seed, scale=0.02)
+    assert abs(mg.checksum(w, SAM_PREFIX + "image_encoder.") - fx["wsum"]) < 1e-6 * fx["wsum"]
+    img = mg.sam_h_width_inputs(seed)
+    assert abs(float(img.double().abs().sum()) - fx["insum"]) < 1e-6 * fx["insum"]
+    with torch.no_grad():
+        emb = O.sam_image_encoder(w, cfg, img)
+    _close(emb[:, ::4, ::2, ::2], fx["emb"], 3e-5)
