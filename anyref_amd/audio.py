@@ -17,8 +17,9 @@ ImageBind that AnyRef keeps (`model/anyref.py:140-161` deletes every other modal
 
 Parameter names match the reference's `audio_encoder` state_dict, so
 `load_state_dict({k[len("model.audio_encoder."):]: v ...})` of an AnyRef checkpoint works.
-Parity: the reference module needs timm/ftfy/iopath (absent here), so this restatement is pinned
-only by its own unit test — **parity unpinned** w.r.t. the reference.
+Parity: pinned at the real audio size (768 / 12 blocks / 12 heads / 1024-d head, 3 clips of 128 x 204) against
+outputs of the reference's own `ImageBindModel.get_audio_feature`, run in the build container with inert
+stand-ins for the three imports this image lacks (`tests/golden/make_golden_audio.py` -> `imagebind_audio.npz`).
 """
 from __future__ import annotations
 
@@ -80,6 +81,22 @@ class ImageBindAudio(nn.Module):
         post[1].register_buffer("log_logit_scale", torch.tensor(math.log(logit_scale)))
         self.modality_postprocessors = nn.ModuleDict({"audio": post})
         self.out_dim = out_dim
+
+    def load_reference_state_dict(self, sd):
+        """Load `imagebind_huge.pth` (full ImageBind: the other five modalities are skipped, anyref.py:142-147) or an
+        AnyRef checkpoint's `model.audio_encoder.*` slice."""
+        pre = "model.audio_encoder."
+        own = set(self.state_dict().keys())
+        pick = {}
+        for k, v in sd.items():
+            k = k[len(pre):] if k.startswith(pre) else k
+            if k in own:
+                pick[k] = v
+        missing = own - set(pick)
+        if missing:
+            raise KeyError(f"audio trunk weights missing: {sorted(missing)[:4]} ...")
+        self.load_state_dict(pick, strict=True)
+        return self
 
     @torch.no_grad()
     def get_audio_feature(self, inputs: torch.Tensor, modality_type=None):

@@ -113,13 +113,20 @@ int anyref_project_audio(anyref_handle* h, void* stream, const float* audio_emb,
   GUARD(h, h->m->project_audio((hipStream_t)stream, audio_emb, n, out));
 }
 
+int anyref_seg_tail(anyref_handle* h, void* stream, const float* sam_images, const int64_t* ids,
+                    const int32_t* ids_lens, const int32_t* ref_pos, int B, int Lmax, int teacher, const float* hidden,
+                    int hidden_rows, const float* attn_mean, const int32_t* resized_hw, const int32_t* orig_hw,
+                    int32_t* out_nseg, float* out_masks, int64_t out_masks_cap, int64_t* mask_offsets, float* out_low) {
+  GUARD(h, h->m->seg_tail((hipStream_t)stream, sam_images, ids, ids_lens, ref_pos, B, Lmax, teacher, hidden,
+                          hidden_rows, attn_mean, resized_hw, orig_hw, out_nseg, out_masks, out_masks_cap,
+                          mask_offsets, out_low));
+}
+
 int anyref_set_seg_range(anyref_handle* h, int lo, int hi) { GUARD(h, h->m->set_seg_range(lo, hi)); }
 
 int anyref_set_overlap(anyref_handle* h, int on) { GUARD(h, h->m->set_overlap(on != 0)); }
 
 int anyref_set_graphs(anyref_handle* h, int on) { GUARD(h, h->m->set_graphs(on != 0)); }
-
-int anyref_set_persistent_decode(anyref_handle* h, int on) { GUARD(h, h->m->set_persistent_decode(on != 0)); }
 
 int anyref_profile_enable(anyref_handle* h, int on) {
   GUARD(h, {

@@ -537,9 +537,25 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(AttnArgs a, int HD) {
 }
 
 // per-stream partial-result workspace (grown on demand, like the split-K slabs in gemm.hip)
+namespace {
+struct AttnWs { hipStream_t s; float* p; size_t cap; };
+std::vector<AttnWs>& attn_pool() {
+  static thread_local std::vector<AttnWs> pool;
+  return pool;
+}
+}  // namespace
+void attn_release_workspace(hipStream_t s) {
+  auto& pool = attn_pool();
+  for (size_t i = 0; i < pool.size(); ++i)
+    if (pool[i].s == s) {
+      (void)hipFree(pool[i].p);
+      pool.erase(pool.begin() + i);
+      return;
+    }
+}
 static float* attn_workspace(hipStream_t s, size_t bytes) {
-  struct Ws { hipStream_t s; float* p; size_t cap; };
-  static thread_local std::vector<Ws> pool;
+  using Ws = AttnWs;
+  auto& pool = attn_pool();
   for (auto& w : pool)
     if (w.s == s) {
       if (w.cap < bytes) {

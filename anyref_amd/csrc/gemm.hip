@@ -563,9 +563,16 @@ __global__ __launch_bounds__(256) void splitk_reduce_norm_kernel(const float* __
 }
 
 // per-stream slab workspace (grown on demand; streams never share one)
+namespace {
+struct SplitKWs { hipStream_t s; float* p; size_t cap; };
+std::vector<SplitKWs>& splitk_pool() {
+  static thread_local std::vector<SplitKWs> pool;
+  return pool;
+}
+}  // namespace
 static float* splitk_workspace(hipStream_t s, size_t bytes) {
-  struct Ws { hipStream_t s; float* p; size_t cap; };
-  static thread_local std::vector<Ws> pool;
+  using Ws = SplitKWs;
+  auto& pool = splitk_pool();
   for (auto& w : pool)
     if (w.s == s) {
       if (w.cap < bytes) {
@@ -604,6 +611,15 @@ static const GemmKnobs& knobs() {
 // make sure `s` owns a split-K workspace of at least `bytes` (call before capturing `s` into a graph:
 // growing the workspace synchronises the stream)
 void gemm_reserve_workspace(hipStream_t s, size_t bytes) { (void)splitk_workspace(s, bytes); }
+void gemm_release_workspace(hipStream_t s) {
+  auto& pool = splitk_pool();
+  for (size_t i = 0; i < pool.size(); ++i)
+    if (pool[i].s == s) {
+      (void)hipFree(pool[i].p);
+      pool.erase(pool.begin() + i);
+      return;
+    }
+}
 
 template <typename T>
 void launch_gemm(const GemmArgs& a_in, hipStream_t s) {

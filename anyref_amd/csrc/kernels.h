@@ -100,6 +100,9 @@ struct GemmArgs {
 template <typename T>
 void launch_gemm(const GemmArgs& a, hipStream_t s);
 void gemm_reserve_workspace(hipStream_t s, size_t bytes);
+// free the split-K slab / attention partial workspaces pooled for a stream that is about to be destroyed
+void gemm_release_workspace(hipStream_t s);
+void attn_release_workspace(hipStream_t s);
 
 // Small-M weight-streaming GEMV for the decode step (HBM-bound):
 // y[b, n] = act(sum_k xn[b,k] W[n,k]) (+ resid) where xn = rmsnorm(x) * gain if gain != null.
@@ -298,36 +301,6 @@ void launch_rephrase(const float* hidden_b, int D, const float* attn_row, int s0
 // convert generic dtype weight to f32 (dtype codes of anyref_hip.h)
 void launch_to_f32(const void* in, int dtype, float* out, int64_t n, hipStream_t s);
 
-// ---- persistent decode-step kernel (decode.hip) ----
-struct DecodeLayerPtrs {
-  const float* in_gain;    // input_layernorm.weight
-  const float* post_gain;  // post_attention_layernorm.weight
-  const void* qkv;         // [3H, H] fused q,k,v
-  const void* o;           // [H, H]
-  const void* gate;        // [F, H] rows at stride gu_ld (interleaved with up: gu_ld = 2H)
-  const void* up;          // [F, H]
-  const void* down;        // [H, F]
-  void* kc;                // this layer's key cache   [B, maxS, nh, hd]
-  void* vc;                // this layer's value cache
-  int gu_ld;               // row stride of gate / up in elements
-  int qkv_ld, o_ld, down_ld;  // row strides of the other matrices (rows are padded, see model.hip Lin::ld)
-};
-struct DecodeStepArgs {
-  const DecodeLayerPtrs* layers;  // device array [nl]
-  int nl, B, H, F, nh, maxS;
-  float eps, scale;
-  float* x;    // [B, H]  residual stream, in: embedded token, out: last layer's output
-  float* qkv;  // [B, 3H] scratch
-  float* att;  // [B, H]  scratch
-  float* act;  // [B, F]  scratch
-  const int* pos;     // [B] position of the token being decoded
-  const float* rope;  // cos/sin table
-  void* q_keep;       // last layer's rotated queries (rephrase branch) or null
-  unsigned* sync;     // decode_sync_bytes() zero-initialised bytes
-};
-size_t decode_sync_bytes();
-// false: shape not covered (B > 2, head dim other than 64/128, ...) -> caller launches op by op
-template <typename T>
-bool launch_decode_layers(const DecodeStepArgs& a, hipStream_t s);
+
 
 }  // namespace anyref

@@ -50,6 +50,11 @@ class ModelBase {
   virtual void llm_forward(hipStream_t s, const float* embeds, const int32_t* lens, int B, int S, float* hidden,
                            float* logits, const int32_t* attn_q, float* attn_row) = 0;
   virtual void project_audio(hipStream_t s, const float* audio_emb, int n, float* out) = 0;
+  virtual void seg_tail(hipStream_t s, const float* sam_images, const int64_t* ids, const int32_t* ids_lens,
+                        const int32_t* ref_pos, int B, int Lmax, int teacher, const float* hidden, int hidden_rows,
+                        const float* attn_mean, const int32_t* resized_hw, const int32_t* orig_hw,
+                        int32_t* out_nseg, float* out_masks, int64_t out_masks_cap, int64_t* mask_offsets,
+                        float* out_low) = 0;
 
   int64_t device_bytes() const { return bytes_; }
   void set_seg_range(int lo, int hi) {
@@ -61,8 +66,6 @@ class ModelBase {
   void set_overlap(bool on) { overlap_ = on; }
   // hipGraph replay of the greedy decode step (default on)
   void set_graphs(bool on) { use_graphs_ = on; }
-  // all layers of a decode step in one persistent kernel (default off: measured 8 % slower, decode.hip)
-  void set_persistent_decode(bool on) { persistent_decode_ = on; }
   Profiler prof;
   std::string err;
   int n_unknown = 0;
@@ -82,7 +85,6 @@ class ModelBase {
   bool finalized_ = false;
   bool overlap_ = true;
   bool use_graphs_ = true;
-  bool persistent_decode_ = false;
 };
 
 std::unique_ptr<ModelBase> make_model(const anyref_config& cfg, int device);

@@ -129,7 +129,17 @@ class Model : public ModelBase {
     (void)hipSetDevice(device_);
     (void)hipDeviceSynchronize();
     for (auto& kv : decode_graphs_) (void)hipGraphExecDestroy(kv.second);
-    if (cap_stream_) (void)hipStreamDestroy(cap_stream_);
+    // workspaces are pooled per stream handle: drop the ones of the streams this handle owns, or a later
+    // stream that recycles the handle value would inherit them
+    for (hipStream_t st : {cap_stream_, s2_})
+      if (st) {
+        gemm_release_workspace(st);
+        attn_release_workspace(st);
+        (void)hipStreamDestroy(st);
+      }
+    if (ev_fork_) (void)hipEventDestroy(ev_fork_);
+    if (ev_sam_) (void)hipEventDestroy(ev_sam_);
+    if (next_host_) (void)hipHostFree(next_host_);
   }
   const char* mode_name() const override { return sizeof(T) == 2 ? (fp8w_ ? "bf16+fp8w" : "bf16") : "f32"; }
   void finalize() override;
@@ -150,6 +160,11 @@ class Model : public ModelBase {
   void llm_forward(hipStream_t s, const float* embeds, const int32_t* lens, int B, int S, float* hidden,
                    float* logits, const int32_t* attn_q, float* attn_row) override;
   void project_audio(hipStream_t s, const float* audio_emb, int n, float* out) override;
+  void seg_tail(hipStream_t s, const float* sam_images, const int64_t* ids, const int32_t* ids_lens,
+                const int32_t* ref_pos, int B, int Lmax, int teacher, const float* hidden, int hidden_rows,
+                const float* attn_mean, const int32_t* resized_hw, const int32_t* orig_hw, int32_t* out_nseg,
+                float* out_masks, int64_t out_masks_cap, int64_t* mask_offsets, float* out_low) override;
+  void join_sam_public(hipStream_t s) { join_sam(s); }
 
  private:
   // ---- packing helpers ----
@@ -258,7 +273,8 @@ class Model : public ModelBase {
   void run_tail(hipStream_t s, const float* sam_images, int B, const std::vector<int>& seg_b,
                 const std::vector<int>& seg_pos, const std::vector<int>& reph_s, const int32_t* resized_hw,
                 const int32_t* orig_hw, int32_t* out_nseg, float* out_masks, int64_t out_masks_cap,
-                int64_t* mask_offsets, float* out_low);
+                int64_t* mask_offsets, float* out_low, const float* attn_given = nullptr, int attn_n = 0);
+  void join_sam(hipStream_t s);
   // SAM image encoder on a second stream: it depends on nothing but the image, is MFMA-bound, and
   // overlaps the HBM-bound LLM decode (fork at the start of a call, join before the mask decoder).
   void fork_sam(hipStream_t s, const float* sam_images, int B);
@@ -308,8 +324,6 @@ class Model : public ModelBase {
   float *l_x_ = nullptr, *hidden_all_ = nullptr, *l_logits_ = nullptr, *l_xlast_ = nullptr;
   T *l_h_ = nullptr, *l_qkv_ = nullptr, *l_q_ = nullptr, *l_att_ = nullptr, *l_act_ = nullptr;
   float *d_x_ = nullptr, *d_qkv_ = nullptr, *d_att_ = nullptr, *d_act_ = nullptr;
-  DecodeLayerPtrs* llm_dec_ptrs_ = nullptr;  // device array for the persistent decode kernel
-  unsigned* dec_sync_ = nullptr;
   T* d_q_ = nullptr;
   int64_t *ids_dev_ = nullptr, *next_dev_ = nullptr;
   int *lens_dev_ = nullptr, *slen_dev_ = nullptr, *pos_dev_ = nullptr, *kvlen_dev_ = nullptr, *rowmap_dev_ = nullptr,
@@ -577,20 +591,6 @@ void Model<T>::finalize() {
     d_qkv_ = talloc<float>((size_t)MB * 3 * H);
     d_att_ = talloc<float>((size_t)MB * H);
     d_act_ = talloc<float>((size_t)MB * F);
-    dec_sync_ = reinterpret_cast<unsigned*>(dalloc(decode_sync_bytes()));
-    HIP_TRY(hipMemset(dec_sync_, 0, decode_sync_bytes()));
-    {  // per-layer pointer table of the persistent decode kernel
-      const int nl = c.llm_layers;
-      std::vector<DecodeLayerPtrs> hp(nl);
-      for (int i = 0; i < nl; ++i) {
-        LlmLayer& L = llm_layers_[i];
-        hp[i] = DecodeLayerPtrs{L.in_norm.g, L.post_norm.g, L.qkv.w, L.o.w, L.gate_w, L.up_w, L.down.w,
-                                kcache_ + cache_layer_stride_ * i, vcache_ + cache_layer_stride_ * i,
-                                2 * L.gu.stride(), L.qkv.stride(), L.o.stride(), L.down.stride()};
-      }
-      llm_dec_ptrs_ = reinterpret_cast<DecodeLayerPtrs*>(dalloc(sizeof(DecodeLayerPtrs) * nl));
-      HIP_TRY(hipMemcpy(llm_dec_ptrs_, hp.data(), sizeof(DecodeLayerPtrs) * nl, hipMemcpyHostToDevice));
-    }
     d_q_ = talloc<T>((size_t)MB * H);
     ids_dev_ = talloc<int64_t>((size_t)MB * S);
     next_dev_ = talloc<int64_t>(MB);
@@ -861,13 +861,16 @@ void Model<T>::decode_step_graph(hipStream_t s, int B, bool keep_q) {
     llm_decode_step(s, B, keep_q);
     return;
   }
-  const int key = (B * 2 + (keep_q ? 1 : 0)) * 2 + (persistent_decode_ ? 1 : 0);
+  const int key = B * 2 + (keep_q ? 1 : 0);
   auto it = decode_graphs_.find(key);
   if (it == decode_graphs_.end()) {
     if (keep_q) ensure_q_last();
     if (!cap_stream_) HIP_TRY(hipStreamCreateWithFlags(&cap_stream_, hipStreamNonBlocking));
-    // the MFMA decode path (B > 4) uses split-K: its slab workspace must exist before the capture
-    gemm_reserve_workspace(cap_stream_, (size_t)8 * B * std::max(std::max(3 * cfg.llm_dim, 2 * cfg.llm_mlp), cfg.llm_vocab) * 4);
+    // The MFMA decode path (B > 4) uses split-K and a captured graph bakes the slab pointer in: the workspace of
+    // the capture stream is reserved ONCE, for max_batch, before the first capture.  A later capture of any
+    // B <= max_batch then never regrows (= frees) a buffer an earlier graph still points at.
+    gemm_reserve_workspace(cap_stream_, (size_t)8 * cfg.max_batch *
+                                            std::max(std::max(3 * cfg.llm_dim, 2 * cfg.llm_mlp), cfg.llm_vocab) * 4);
     hipGraph_t g = nullptr;
     hipGraphExec_t ge = nullptr;
     HIP_TRY(hipStreamBeginCapture(cap_stream_, hipStreamCaptureModeRelaxed));
@@ -993,21 +996,12 @@ void Model<T>::llm_decode_step(hipStream_t s, int B, bool keep_q) {
   const int H = c.llm_dim, F = c.llm_mlp, nh = c.llm_heads, hd = H / nh, S = c.llm_max_seq, nl = c.llm_layers;
   launch_embed_rows(next_dev_, B, emb_table_, sizeof(T) == 2, H, d_x_, s);
   launch_decode_index(pos_dev_, B, S, rowmap_dev_, kvlen_dev_, s);
-  bool layers_done = false;
-  if (persistent_decode_ && !fp8w_) {
-    DecodeStepArgs da;
-    da.layers = llm_dec_ptrs_; da.nl = nl; da.B = B; da.H = H; da.F = F; da.nh = nh; da.maxS = S;
-    da.eps = c.llm_rms_eps; da.scale = 1.f / sqrtf((float)hd);
-    da.x = d_x_; da.qkv = d_qkv_; da.att = d_att_; da.act = d_act_;
-    da.pos = pos_dev_; da.rope = rope_tab_; da.q_keep = keep_q ? q_last_ : nullptr; da.sync = dec_sync_;
-    layers_done = launch_decode_layers<T>(da, s);
-  }
   // More than 4 sequences per call: the FMA GEMV would stream every weight twice (4 batch rows per pass) and
   // its VALU work grows with B, so the linears go through the MFMA GEMM (M = B rows of a 64/128-row tile,
   // split-K to fill the chip: weights are read once) with the norms / SwiGLU as in prefill.
   const bool mfma_decode = sizeof(T) == 2 && B > 4;
   bool h_ready = false;
-  for (int i = 0; i < nl && !layers_done; ++i) {
+  for (int i = 0; i < nl; ++i) {
     LlmLayer& L = llm_layers_[i];
     T* kc = kcache_ + cache_layer_stride_ * i;
     T* vc = vcache_ + cache_layer_stride_ * i;
@@ -1354,13 +1348,39 @@ int Model<T>::splice_inputs(hipStream_t s, const int64_t* input_ids, const int32
 }
 
 template <typename T>
+void Model<T>::join_sam(hipStream_t s) {
+  if (sam_forked_) HIP_TRY(hipStreamWaitEvent(s, ev_sam_, 0));  // everything after this on `s` sees the image embeddings
+  sam_forked_ = false;
+  sam_head_done_ = false;
+}
+namespace {
+// generate / forward fork the encoder early; whatever path leaves them (a throw included) joins it
+template <typename M>
+struct SamJoinGuard {
+  M* m;
+  hipStream_t s;
+  ~SamJoinGuard() {
+    try {
+      m->join_sam_public(s);
+    } catch (...) {
+    }
+  }
+};
+}  // namespace
+
+template <typename T>
 void Model<T>::run_tail(hipStream_t s, const float* sam_images, int B, const std::vector<int>& seg_b,
                         const std::vector<int>& seg_pos, const std::vector<int>& reph_s, const int32_t* resized_hw,
                         const int32_t* orig_hw, int32_t* out_nseg, float* out_masks, int64_t out_masks_cap,
-                        int64_t* mask_offsets, float* out_low) {
+                        int64_t* mask_offsets, float* out_low, const float* attn_given, int attn_n) {
   // seg_b/seg_pos: (image, row of hidden_all_) of every [SEG]; reph_s: rephrase start row per image
+  // attn_given (seg_tail only): caller's head-mean last-layer attention [B, attn_n, attn_n] instead of the K cache
   const anyref_config& c = cfg;
   const int H = c.llm_dim, S = c.llm_max_seq, nseg = (int)seg_b.size();
+  // join BEFORE anything below can throw: a refused call must not leave the encoder running on the side stream
+  // over the caller's images, nor a stale "forked" flag for the next call
+  const bool sam_ready = sam_forked_;
+  join_sam(s);
   for (int b = 0; b < B; ++b) out_nseg[b] = 0;
   for (int i = 0; i < nseg; ++i) out_nseg[seg_b[i]]++;
   for (int b = 0; b < B; ++b)
@@ -1371,11 +1391,6 @@ void Model<T>::run_tail(hipStream_t s, const float* sam_images, int B, const std
     off += (int64_t)out_nseg[b] * orig_hw[2 * b] * orig_hw[2 * b + 1];
   }
   if (off > out_masks_cap) throw std::runtime_error("out_masks capacity too small");
-  if (sam_forked_) {  // join: everything after this point on `s` sees the image embeddings
-    HIP_TRY(hipStreamWaitEvent(s, ev_sam_, 0));
-  }
-  const bool sam_ready = sam_forked_;
-  sam_forked_ = false;
   if (nseg == 0) return;
   HIP_TRY(hipMemcpyAsync(idx_a_, seg_b.data(), nseg * 4, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(idx_b_, seg_pos.data(), nseg * 4, hipMemcpyHostToDevice, s));
@@ -1392,11 +1407,16 @@ void Model<T>::run_tail(hipStream_t s, const float* sam_images, int B, const std
       done[b] = 1;
       const int e0 = seg_pos[i], s0 = reph_s[b];
       if (e0 <= s0) continue;
-      const int kl = e0 + 1;
-      HIP_TRY(hipMemcpyAsync(kvlen_dev_ + b, &kl, 4, hipMemcpyHostToDevice, s));
-      HIP_TRY(hipStreamSynchronize(s));
-      launch_attn_row_mean<T>(q_last_ + ((size_t)b * S + e0) * H, 0, hd, kc + (size_t)b * S * H, 0, H, hd,
-                              kvlen_dev_ + b, 1, nh, hd, 1.f / sqrtf((float)hd), attn_row_ + (size_t)b * S, S, s);
+      if (attn_given) {
+        HIP_TRY(hipMemcpyAsync(attn_row_ + (size_t)b * S, attn_given + ((size_t)b * attn_n + e0) * attn_n,
+                               (size_t)attn_n * 4, hipMemcpyDeviceToDevice, s));
+      } else {
+        const int kl = e0 + 1;
+        HIP_TRY(hipMemcpyAsync(kvlen_dev_ + b, &kl, 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        launch_attn_row_mean<T>(q_last_ + ((size_t)b * S + e0) * H, 0, hd, kc + (size_t)b * S * H, 0, H, hd,
+                                kvlen_dev_ + b, 1, nh, hd, 1.f / sqrtf((float)hd), attn_row_ + (size_t)b * S, S, s);
+      }
       launch_rephrase(hidden_all_ + (size_t)b * S * H, H, attn_row_ + (size_t)b * S, s0, e0, c.rephrase_weight,
                       seg_h_ + (size_t)i * H, s);
     }
@@ -1437,6 +1457,7 @@ void Model<T>::generate(hipStream_t s, const float* clip_images, const float* sa
   const bool keep_q = c.rephrase_weight > 0.f;
 
   sam_head_done_ = false;
+  SamJoinGuard<Model<T>> join_guard{this, s};
   fork_sam_head(s, sam_images, B);
   clip_tower(s, clip_images, B);
   std::vector<int> slen, img_pos;
@@ -1523,6 +1544,7 @@ void Model<T>::forward_teacher(hipStream_t s, const float* clip_images, const fl
   const int H = c.llm_dim, S = c.llm_max_seq, n_img = clip_n_;
   const bool keep_q = c.rephrase_weight > 0.f;
   sam_head_done_ = false;
+  SamJoinGuard<Model<T>> join_guard{this, s};
   fork_sam(s, sam_images, B);
   clip_tower(s, clip_images, B);
   std::vector<int> slen, img_pos;
@@ -1551,6 +1573,42 @@ void Model<T>::forward_teacher(hipStream_t s, const float* clip_images, const fl
            mask_offsets, out_low);
   if (out_hidden)
     HIP_TRY(hipMemcpyAsync(out_hidden, hidden_all_, (size_t)B * S * H * 4, hipMemcpyDeviceToDevice, s));
+}
+
+template <typename T>
+void Model<T>::seg_tail(hipStream_t s, const float* sam_images, const int64_t* ids, const int32_t* ids_lens,
+                        const int32_t* ref_pos, int B, int Lmax, int teacher, const float* hidden, int hidden_rows,
+                        const float* attn_mean, const int32_t* resized_hw, const int32_t* orig_hw, int32_t* out_nseg,
+                        float* out_masks, int64_t out_masks_cap, int64_t* mask_offsets, float* out_low) {
+  HIP_TRY(hipSetDevice(device_));
+  const anyref_config& c = cfg;
+  if (!finalized_) throw std::runtime_error("seg_tail before finalize");
+  if (B <= 0 || B > c.max_batch) throw std::runtime_error("batch exceeds max_batch");
+  const int H = c.llm_dim, S = c.llm_max_seq, shift = clip_n_ - 1;  // the reference's hard-coded "+255"
+  if (hidden_rows <= 0 || hidden_rows > S) throw std::runtime_error("hidden_rows exceeds llm_max_seq");
+  if (c.rephrase_weight > 0.f && !attn_mean) throw std::runtime_error("rephrase_weight > 0 needs attn_mean");
+  for (int b = 0; b < B; ++b)
+    HIP_TRY(hipMemcpyAsync(hidden_all_ + (size_t)b * S * H, hidden + (size_t)b * hidden_rows * H,
+                           (size_t)hidden_rows * H * 4, hipMemcpyDeviceToDevice, s));
+  std::vector<int> seg_b, seg_pos, reph(B, 0);
+  for (int b = 0; b < B; ++b) {
+    if (ids_lens[b] <= 0 || ids_lens[b] > Lmax) throw std::runtime_error("bad sequence length");
+    const int64_t* row = ids + (size_t)b * Lmax;
+    // generate: [SEG] in output_ids[:,1:] at p -> hidden row p + 255 (anyref.py:723-726,:758);
+    // forward:  [SEG] in input_ids at p       -> hidden row p - 1 + 255 (anyref.py:273-282)
+    for (int p = 1; p < ids_lens[b]; ++p)
+      if (row[p] >= c.seg_lo && row[p] <= c.seg_hi) {
+        const int hp = p - 1 + shift;
+        if (hp >= hidden_rows) continue;
+        seg_b.push_back(b);
+        seg_pos.push_back(hp);
+      }
+    // generate: prompt length L -> L - 1 + 255 (:745); forward: where(labels > 0)[0][0] - 1 + 255 (:378)
+    reph[b] = ref_pos ? ref_pos[b] - 1 + shift : 0;
+  }
+  (void)teacher;  // both searches land on the same row arithmetic; kept in the ABI to name the caller's convention
+  run_tail(s, sam_images, B, seg_b, seg_pos, reph, resized_hw, orig_hw, out_nseg, out_masks, out_masks_cap,
+           mask_offsets, out_low, attn_mean, hidden_rows);
 }
 
 std::unique_ptr<ModelBase> make_model(const anyref_config& cfg, int device) {

@@ -60,11 +60,16 @@ def _c_config(cfg: AnyRefConfig, mode: int, max_batch: int, max_seg: int) -> _li
     return c
 
 
+_NEEDS_HANDLE = frozenset({
+    "generate", "model_forward_new", "forward", "__call__", "encode_images", "sam_encode", "mask_decode", "llm_forward",
+    "seg_tail", "postprocess", "device_bytes", "set_overlap", "set_graphs", "profile_enable", "profile_read"})
+
+
 class AnyRefForCausalLM:
     """MI355X-native stand-in for `model.anyref.AnyRefForCausalLM` (inference surface)."""
 
     def __init__(self, cfg: AnyRefConfig, mode: str = "perf", device: int = 0, max_batch: int = 1,
-                 max_seg: int = 4, audio_encoder=None, **kwargs):
+                 max_seg: int = 4, audio_encoder=None, defer: bool = False, **kwargs):
         # constructor kwargs of the reference (anyref.py:188-209) that shape the path
         if "seg_token_idx" in kwargs:
             cfg.seg_token_idx = kwargs.pop("seg_token_idx")
@@ -75,6 +80,9 @@ class AnyRefForCausalLM:
         self.ce_loss_weight = kwargs.pop("ce_loss_weight", 1.0)
         self.dice_loss_weight = kwargs.pop("dice_loss_weight", 0.5)
         self.bce_loss_weight = kwargs.pop("bce_loss_weight", 2.0)
+        self.vision_pretrained = kwargs.pop("vision_pretrained", None)
+        self.add_audio_encoder = bool(kwargs.pop("add_audio_encoder", False))
+        self.imagebind_ckpt = kwargs.pop("imagebind_ckpt", "model/ImageBind/imagebind_huge.pth")
         self.cfg = cfg
         self.mode = {"parity": _lib.MODE_PARITY, "perf": _lib.MODE_PERF, "perf_fp8w": _lib.MODE_PERF_FP8W}[mode]
         self.mode_name = mode
@@ -84,18 +92,46 @@ class AnyRefForCausalLM:
         self.audio_encoder = audio_encoder      # PyTorch-ROCm ImageBind audio trunk (anyref_amd.audio)
         self.config = SimpleNamespace(eos_token_id=cfg.eos_token_id, bos_token_id=cfg.bos_token_id,
                                       pad_token_id=cfg.pad_token_id, hidden_size=cfg.llm.dim,
-                                      vocab_size=cfg.llm.vocab, use_cache=True)
+                                      vocab_size=cfg.llm.vocab, use_cache=True, out_dim=cfg.out_dim,
+                                      mm_vision_tower=kwargs.pop("vision_tower", "openai/clip-vit-large-patch14"))
+        self.h = None
+        self._finalized = False
+        # `from_pretrained` flow: weights are gathered on the host first (base checkpoint, CLIP tower, SAM file,
+        # token-row resize, LoRA merge all happen BEFORE `.cuda()` in the callers) and go to HBM in one build
+        self._host_sd: Optional[Dict[str, torch.Tensor]] = {} if defer else None
+        if not defer:
+            self._create()
+
+    def _create(self):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise RuntimeError("AnyRefForCausalLM needs an MI355X: the HIP backend has no CPU fallback")
         h = C.c_void_p()
-        cc = _c_config(cfg, self.mode, max_batch, max_seg)
-        rc = self.lib.anyref_create(C.byref(cc), device, C.byref(h))
+        cc = _c_config(self.cfg, self.mode, self.max_batch, self.max_seg)
+        rc = self.lib.anyref_create(C.byref(cc), self.device_index, C.byref(h))
         if rc != 0:
             raise RuntimeError("anyref_create: " + self.lib.anyref_last_error(None).decode())
         self.h = h
-        self._finalized = False
-        self.n_img = cfg.clip.n_patches
+
+    @property
+    def n_img(self) -> int:
+        return self.cfg.clip.n_patches
+
+    def _ensure_built(self):
+        """Deferred construction: create the handle for the FINAL config and move the gathered weights to HBM."""
+        if self.h is not None:
+            return
+        from .checkpoint import missing_for
+        sd = self._host_sd or {}
+        audio = any(k.startswith("model.audio_projector.") for k in sd)
+        miss = missing_for(self.cfg, sd.keys(), audio)
+        if miss:
+            raise RuntimeError(f"{len(miss)} weights of the inference path were never loaded, e.g. {miss[:4]} "
+                               "(from_pretrained -> initialize_vision_modules -> initialize_anyref_modules -> adapter)")
+        self.config.vocab_size = self.cfg.llm.vocab
+        self._create()
+        self.load_state_dict(sd)
+        self._host_sd = None
 
     # ---- lifetime ------------------------------------------------------------------------
     def __del__(self):
@@ -107,6 +143,12 @@ class AnyRefForCausalLM:
                 pass
             self.h = None
 
+    def __getattribute__(self, name):
+        # any method that talks to the C-ABI handle first makes sure a deferred build has happened
+        if name in _NEEDS_HANDLE:
+            object.__getattribute__(self, "_ensure_built")()
+        return object.__getattribute__(self, name)
+
     def _check(self, rc: int, what: str):
         if rc != 0:
             raise RuntimeError(f"{what}: {self.lib.anyref_last_error(self.h).decode()}")
@@ -116,6 +158,9 @@ class AnyRefForCausalLM:
 
     # ---- weights (reference state_dict names) --------------------------------------------
     def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = False):
+        if self.h is None:                       # deferred build: keep gathering on the host
+            self._host_sd.update(sd)
+            return [], []
         for name, t in sd.items():
             if t.dtype not in _DT:
                 t = t.float()
@@ -133,27 +178,124 @@ class AnyRefForCausalLM:
         m.load_state_dict(sd)
         return m
 
-    # ---- plumbing the reference's eval scripts call (eval_referseg.py:70-88) ---------------
+    # ---- construction path of the reference's callers (eval_referseg.py:62-88) --------------
+    @classmethod
+    def from_pretrained(cls, model_version: str, torch_dtype=None, mode: Optional[str] = None, device: int = 0,
+                        max_batch: int = 1, max_seg: int = 4, max_seq: int = 1024, **model_args):
+        """`AnyRefForCausalLM.from_pretrained(model_version, torch_dtype=..., **model_args)` (eval_referseg.py:70-72)
+        on an HF `save_pretrained` directory (sharded safetensors / bin): config.json -> LLM shape, every tensor ->
+        host state dict under the reference's names.  `model_args` are the reference constructor's kwargs
+        (anyref.py:188-209: seg_token_idx, out_dim, vision_pretrained, add_audio_encoder, rephrase_weight, ...).
+        The handle is built at `.cuda()` / first use, after the caller's `initialize_*`, `resize_token_embeddings`
+        and adapter merge.  `torch_dtype` is accepted for signature parity; the arithmetic type is `mode`
+        ("perf" = bf16 storage, fp32 accumulate; "parity" = fp32), default perf."""
+        import json
+        import os
+        from .checkpoint import read_hf_dir, llm_config_from_hf
+        hf = json.load(open(os.path.join(model_version, "config.json")))
+        cfg = AnyRefConfig(llm=llm_config_from_hf(hf, max_seq))
+        for k in ("eos_token_id", "bos_token_id", "pad_token_id"):
+            if hf.get(k) is not None:
+                setattr(cfg, k, int(hf[k]))
+        model_args.pop("train_mask_decoder", None)
+        if "mm_vision_tower" in hf:
+            model_args.setdefault("vision_tower", hf["mm_vision_tower"])
+        m = cls(cfg, mode=mode or "perf", device=device, max_batch=max_batch, max_seg=max_seg, defer=True, **model_args)
+        m._host_sd.update(read_hf_dir(model_version))
+        # a merged checkpoint (merge_lora.py:62 `save_pretrained`) already carries the towers: size them from it
+        if "train_mask_decoder" in hf and m.vision_pretrained:
+            m._adopt_sam_shape()
+        return m
+
+    def _adopt_sam_shape(self):
+        from .checkpoint import sam_config_for
+        s = self.cfg.sam
+        self.cfg.sam = sam_config_for(self.vision_pretrained, img_size=s.img_size, patch=s.patch, window=s.window,
+                                      out_chans=s.out_chans)
+
     def get_model(self):
         return self
 
     def get_vision_tower(self):
         return self
 
-    def initialize_vision_modules(self, *_a, **_k):
+    def initialize_vision_modules(self, model_args=None, *_a, **_k):
+        """LLaVA's `initialize_vision_modules` (eval_referseg.py:77): load the CLIP tower named by
+        `config.mm_vision_tower` (a local HF directory) unless the checkpoint already carries it."""
+        if self._host_sd is None:
+            return None
+        from .synth import CLIP_PREFIX
+        if any(k.startswith(CLIP_PREFIX) for k in self._host_sd):
+            return None
+        from .checkpoint import load_clip_tower
+        path = getattr(model_args, "mm_vision_tower", None) or self.config.mm_vision_tower
+        self.cfg.clip, sd = load_clip_tower(path)
+        self._host_sd.update(sd)
         return None
 
-    def initialize_anyref_modules(self, *_a, **_k):
+    def initialize_anyref_modules(self, config=None, *_a, **_k):
+        """`initialize_anyref_modules` (anyref.py:96-161): SAM from `vision_pretrained` (variant by substring),
+        `text_hidden_fcs` and, with `add_audio_encoder`, `audio_projector` freshly initialised as `nn.Linear` does
+        (their trained values come with the adapter's `modules_to_save`), ImageBind trunk attached if its file exists."""
+        if self._host_sd is None:
+            return None
+        import os
+        from .checkpoint import load_sam
+        from .synth import SAM_PREFIX
+        sd = self._host_sd
+        if self.vision_pretrained is None:
+            raise ValueError("initialize_anyref_modules needs the `vision_pretrained` constructor kwarg (anyref.py:98-105)")
+        self._adopt_sam_shape()
+        if not any(k.startswith(SAM_PREFIX) for k in sd):
+            sd.update(load_sam(self.vision_pretrained))
+        H, out = self.cfg.llm.dim, self.cfg.out_dim
+
+        def fresh(name, n_out, n_in):
+            if name + ".weight" not in sd:
+                lin = torch.nn.Linear(n_in, n_out)
+                sd[name + ".weight"], sd[name + ".bias"] = lin.weight.detach(), lin.bias.detach()
+
+        fresh("model.text_hidden_fcs.0.0", H, H)
+        fresh("model.text_hidden_fcs.0.2", out, H)
+        if self.add_audio_encoder:
+            fresh("model.audio_projector", H, self.cfg.audio_dim)
+            if self.audio_encoder is None:
+                from .audio import ImageBindAudio
+                self.audio_encoder = ImageBindAudio()
+                if os.path.exists(self.imagebind_ckpt):
+                    from .checkpoint import read_tensors
+                    self.audio_encoder.load_reference_state_dict(read_tensors(self.imagebind_ckpt))
+                else:
+                    print("ImageBind audio encoder ckpt not found!")
         return None
 
     def resize_token_embeddings(self, n: int):
-        if n != self.cfg.llm.vocab:
-            raise ValueError(f"tokenizer has {n} tokens but the backend was built for vocab {self.cfg.llm.vocab}")
+        if self._host_sd is None:
+            if n != self.cfg.llm.vocab:
+                raise ValueError(f"tokenizer has {n} tokens but the backend was built for vocab {self.cfg.llm.vocab}")
+            return
+        from .checkpoint import resize_token_rows
+        resize_token_rows(self._host_sd, n)
+        self.cfg.llm.vocab = n
+        self.config.vocab_size = n
+
+    def merge_adapter(self, adapter_dir: str):
+        """`PeftModel.from_pretrained(model, dir).merge_and_unload()` (anyref_amd.peft_compat)."""
+        if self._host_sd is None:
+            raise RuntimeError("the LoRA merge happens on the host state dict: call it before .cuda() / first use")
+        from .checkpoint import merge_lora
+        self.adapter_stats = merge_lora(self._host_sd, adapter_dir)
+        return self
+
+    def host_state_dict(self):
+        """The gathered weights before the build (deferred construction only)."""
+        return self._host_sd
 
     def eval(self):
         return self
 
     def cuda(self, *_a):
+        self._ensure_built()
         return self
 
     def half(self):
@@ -169,6 +311,8 @@ class AnyRefForCausalLM:
     def set_seg_token_idx(self, seg_token_idx):
         """`seg_token_idx` kwarg of the reference constructor (anyref.py:197-200), changeable later."""
         self.cfg.seg_token_idx = seg_token_idx
+        if self.h is None:
+            return
         lo, hi = self.cfg.seg_range()
         self._check(self.lib.anyref_set_seg_range(self.h, lo, hi), "set_seg_range")
 
@@ -179,10 +323,6 @@ class AnyRefForCausalLM:
     def set_graphs(self, on: bool):
         """hipGraph replay of the greedy decode step (default) or eager launches."""
         self._check(self.lib.anyref_set_graphs(self.h, int(on)), "set_graphs")
-
-    def set_persistent_decode(self, on: bool):
-        """One persistent kernel per decode step, or (default) one launch per GEMV / attention."""
-        self._check(self.lib.anyref_set_persistent_decode(self.h, int(on)), "set_persistent_decode")
 
     # ---- per-kernel timing for bench.py ------------------------------------------------------
     def profile_enable(self, on: bool, only_tag: Optional[str] = None, sample_every: int = 1):
@@ -228,10 +368,17 @@ class AnyRefForCausalLM:
             ids = ids[None]
         B, Lm = ids.shape
         rows = []
+        pad = self.config.pad_token_id
         for b in range(B):
             r = ids[b]
             if attention_masks is not None:
                 r = r[attention_masks[b].to("cpu").bool()]
+            elif B > 1 and pad is not None:
+                # the callers' batched path passes left-padded ids and NO mask (eval_referseg.py:124-137); the
+                # collator's own mask is `input_ids.ne(pad_token_id)` (utils/coco_instance.py:142): strip the pad
+                # runs at both ends of the row (pad = unk never opens or closes a prompt: BOS ... "ASSISTANT:")
+                keep = (r != int(pad)).nonzero().flatten()
+                r = r[int(keep[0]): int(keep[-1]) + 1] if len(keep) else r[:1]
             rows.append(r)
         lens = torch.tensor([len(r) for r in rows], dtype=torch.int32)
         out = torch.zeros(B, int(lens.max()), dtype=torch.long)
@@ -351,6 +498,34 @@ class AnyRefForCausalLM:
         self._check(self.lib.anyref_llm_forward(self.h, self._stream(), _ptr(x), ln, B, S, _ptr(hidden), _ptr(logits),
                                                 aq, _ptr(ar)), "llm_forward")
         return dict(hidden=hidden, logits=logits, attn_row=ar)
+
+    def seg_tail(self, sam_images, ids, ids_lens, ref_pos, hidden, attn_mean, sam_resized_sizes, height, width,
+                 teacher: bool = False):
+        """The glue alone (anyref.py:718-822 / :273-282,:356-430) on caller-provided LLM outputs:
+        ids [B,L] (`outputs.sequences` or, teacher=True, `input_ids`), hidden [B,rows,H] = `hidden_states[-1]`,
+        attn_mean [B,rows,rows] head-mean `attentions[-1]` (only with rephrase_weight > 0), ref_pos [B] = prompt
+        length (generate) or `where(labels > 0)[0][0]` (forward).  -> (pred_masks list | None, nseg)."""
+        ids = ids.detach().to("cpu", torch.long).contiguous()
+        B, Lmax = ids.shape
+        lens = torch.tensor([int(v) for v in ids_lens], dtype=torch.int32)
+        rp = None if ref_pos is None else torch.tensor([int(v) for v in ref_pos], dtype=torch.int32)
+        hid = hidden.to(self.device, torch.float32).contiguous()
+        att = None if attn_mean is None else attn_mean.to(self.device, torch.float32).contiguous()
+        sam = sam_images.to(self.device, torch.float32).contiguous()
+        height, width = [int(h) for h in height], [int(w) for w in width]
+        rs = torch.tensor([[int(a), int(b)] for a, b in sam_resized_sizes], dtype=torch.int32).contiguous()
+        os_ = torch.tensor([[h, w] for h, w in zip(height, width)], dtype=torch.int32).contiguous()
+        nseg = torch.zeros(B, dtype=torch.int32)
+        offs = torch.zeros(B, dtype=torch.long)
+        cap = sum(self.max_seg * h * w for h, w in zip(height, width))
+        out_masks = torch.empty(cap, device=self.device, dtype=torch.float32)
+        self._check(self.lib.anyref_seg_tail(self.h, self._stream(), _ptr(sam), _ptr(ids), _ptr(lens), _ptr(rp), B, Lmax,
+                                             int(teacher), _ptr(hid), hid.shape[1], _ptr(att), _ptr(rs), _ptr(os_),
+                                             _ptr(nseg), _ptr(out_masks), cap, _ptr(offs), None), "seg_tail")
+        if int(nseg.sum()) == 0:
+            return None, nseg
+        return [out_masks[int(offs[b]): int(offs[b]) + int(nseg[b]) * height[b] * width[b]].view(int(nseg[b]), height[b], width[b])
+                for b in range(B)], nseg
 
     # ---- the reference surface -------------------------------------------------------------
     @torch.no_grad()

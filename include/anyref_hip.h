@@ -152,6 +152,29 @@ int anyref_llm_forward(anyref_handle* h, void* stream, const float* embeds, cons
  * out f32 [n, llm_dim] dev, ready to be passed as `extra_embeds`. */
 int anyref_project_audio(anyref_handle* h, void* stream, const float* audio_emb, int n, float* out);
 
+/*
+ * The glue alone: everything `generate` does after `super().generate` returns (model/anyref.py:718-822) or
+ * `model_forward_new` does around `super().forward` (:273-282, :356-430), on caller-provided LLM outputs --
+ * [SEG] search, hidden-row gather with the reference's hard-coded image offset (+255 = n_patches - 1),
+ * rephrase, text_hidden_fcs, SAM image encoder, per-image prompt encoder -> mask decoder -> postprocess.
+ * This is the entry the parity tests hold against fixtures made by running the reference's own lines on
+ * canned LLM outputs (tests/golden/make_golden_glue.py).
+ *   ids        i64 host [B, Lmax]: `outputs.sequences` (teacher = 0) or `input_ids` (teacher = 1);
+ *              a [SEG] at index p >= 1 takes hidden row p - 1 + 255 (which is `where(ids[:,1:]) + 255`
+ *              of :723-726,:758 and `pos - 1 + 255` of :282)
+ *   ids_lens   i32 host [B]
+ *   ref_pos    i32 host [B] or NULL: rephrase start = ref_pos[b] - 1 + 255 (teacher = 0: the prompt length,
+ *              :745; teacher = 1: `where(labels > 0)[0][0]`, :378)
+ *   hidden     f32 dev [B, hidden_rows, llm_dim] = `hidden_states[-1]`
+ *   attn_mean  f32 dev [B, hidden_rows, hidden_rows] head-mean `attentions[-1]`, needed iff rephrase_weight > 0
+ *   outputs as anyref_generate.
+ */
+int anyref_seg_tail(anyref_handle* h, void* stream, const float* sam_images, const int64_t* ids,
+                    const int32_t* ids_lens, const int32_t* ref_pos, int B, int Lmax, int teacher,
+                    const float* hidden, int hidden_rows, const float* attn_mean, const int32_t* resized_hw,
+                    const int32_t* orig_hw, int32_t* out_nseg, float* out_masks, int64_t out_masks_cap,
+                    int64_t* mask_offsets, float* out_low);
+
 /* Change the inclusive [SEG] id range after creation (`seg_token_idx` kwarg, anyref.py:197-200). */
 int anyref_set_seg_range(anyref_handle* h, int lo, int hi);
 
@@ -163,13 +186,6 @@ int anyref_set_overlap(anyref_handle* h, int on);
  * arguments (position / next token live on the device), captured once per batch size.  0 launches
  * them eagerly; the per-kernel profiler below always runs eagerly. */
 int anyref_set_graphs(anyref_handle* h, int on);
-
-/* Persistent decode kernel (default 0): all LLM layers of one greedy step run in a single launch
- * whose workgroups meet at grid barriers (csrc/decode.hip), bit-identical to the op-by-op path.
- * Kept as a measured alternative: on MI355X it is ~8 % slower per step than one launch per GEMV /
- * attention.  Shapes it does not cover (batch > 2 per call, head dim other than
- * 64/128) always use the op-by-op path. */
-int anyref_set_persistent_decode(anyref_handle* h, int on);
 
 /*
  * Per-kernel timing for the measurement harness (bench.py "roofline"): when enabled, every GEMM /

@@ -52,7 +52,7 @@ def glue_cfg():
     return AnyRefConfig(
         clip=ClipConfig(image_size=224, patch=14, dim=32, heads=2, layers=2, mlp=64),
         llm=LlmConfig(vocab=VOCAB, dim=H_LLM, heads=HEADS, layers=1, mlp=96, max_seq=512),
-        sam=SamConfig(img_size=224, patch=16, dim=96, depth=2, heads=2, window=14, global_idx=(1,)),
+        sam=SamConfig(img_size=224, patch=16, dim=128, depth=2, heads=2, window=14, global_idx=(1,)),
         seg_token_idx=SEG)
 
 

@@ -36,3 +36,22 @@ def test_audio_feature_contract_and_math():
     ref = t + a
     ref = ref + blk.mlp.fc2(torch.nn.functional.gelu(blk.mlp.fc1(blk.norm_2(ref))))
     assert torch.allclose(blk(t), ref, atol=1e-5)
+
+
+def test_audio_trunk_against_reference_fixture():
+    """The restatement at ImageBind's real audio size against outputs of the reference's own
+    `ImageBindModel.get_audio_feature` (imagebind_model.py:477-511) run in the build container
+    (tests/golden/make_golden_audio.py)."""
+    import os
+    import sys
+    import numpy as np
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    import make_golden_audio as ga
+    fx = np.load(os.path.join(here, "golden", "imagebind_audio.npz"))
+    m = ga.seeded_audio_module()
+    wsum = sum(float(v.double().abs().sum()) for v in m.state_dict().values())
+    assert abs(wsum - float(fx["wsum"])) < 1e-6 * float(fx["wsum"]), "seeded weights drifted"
+    feat, emb = m.get_audio_feature(ga.audio_inputs())
+    assert np.abs(feat.numpy() - fx["feat"]).max() < 2e-5 * max(1.0, np.abs(fx["feat"]).max())
+    assert np.abs(emb.numpy() - fx["emb"]).max() < 2e-5 * np.abs(fx["emb"]).max()

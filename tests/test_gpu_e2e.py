@@ -155,9 +155,9 @@ def test_rephrase_and_teacher_forward():
 @pytest.mark.parametrize("mode", ["parity", "perf"])
 @pytest.mark.parametrize("B", [1, 2])
 def test_decode_launch_modes_bit_identical(mode, B):
-    """The decode step has three launch modes -- eager op by op, hipGraph replay, and the persistent
-    grid-barrier kernel (csrc/decode.hip) -- that share one work decomposition: ids, hidden states and
-    mask logits must agree bit for bit, alone and with the SAM encoder on the second stream."""
+    """The decode step has two launch modes -- eager op by op and hipGraph replay -- that share one work
+    decomposition: ids, hidden states and mask logits must agree bit for bit, alone and with the SAM encoder on
+    the second stream."""
     from anyref_amd.model import AnyRefForCausalLM
     cfg = config_tiny()
     sd = synth_state_dict(cfg, seed=5, scale=0.05)
@@ -166,26 +166,24 @@ def test_decode_launch_modes_bit_identical(mode, B):
     sizes, H, W = [(224, 224)] * B, [224] * B, [224] * B
     m = AnyRefForCausalLM.from_state_dict(cfg, {k: v.cuda() for k, v in sd.items()}, mode=mode, max_batch=B, max_seg=4)
     m.config.eos_token_id = None
-    m.set_graphs(False); m.set_persistent_decode(False)
+    m.set_graphs(False)
     out0, _, _ = m.generate(clip, ids_p, sam, sizes, H, W, max_new_tokens=5)
     m.set_seg_token_idx(int(out0[0, ids_p.shape[1] + 2]))       # a [SEG] for row 0 at least
     ref = None
     for overlap in (False, True):
         for graphs in (False, True):
-            for persistent in (False, True):
-                m.set_overlap(overlap); m.set_graphs(graphs); m.set_persistent_decode(persistent)
-                (o_ids, masks, _), ex = m.generate(clip, ids_p, sam, sizes, H, W, max_new_tokens=12,
-                                                   _return_extras=True)
-                cur = (o_ids.cpu(), ex["hidden"].cpu(), [None if t is None else t.cpu() for t in masks])
-                if ref is None:
-                    ref = cur
-                    assert ref[2][0] is not None
-                    continue
-                tag = f"overlap={overlap} graphs={graphs} persistent={persistent}"
-                assert torch.equal(cur[0], ref[0]), f"ids differ ({tag})"
-                assert torch.equal(cur[1], ref[1]), f"hidden states differ ({tag})"
-                for a, b in zip(cur[2], ref[2]):
-                    assert (a is None) == (b is None) and (a is None or torch.equal(a, b)), f"masks differ ({tag})"
+            m.set_overlap(overlap); m.set_graphs(graphs)
+            (o_ids, masks, _), ex = m.generate(clip, ids_p, sam, sizes, H, W, max_new_tokens=12, _return_extras=True)
+            cur = (o_ids.cpu(), ex["hidden"].cpu(), [None if t is None else t.cpu() for t in masks])
+            if ref is None:
+                ref = cur
+                assert ref[2][0] is not None
+                continue
+            tag = f"overlap={overlap} graphs={graphs}"
+            assert torch.equal(cur[0], ref[0]), f"ids differ ({tag})"
+            assert torch.equal(cur[1], ref[1]), f"hidden states differ ({tag})"
+            for a, b in zip(cur[2], ref[2]):
+                assert (a is None) == (b is None) and (a is None or torch.equal(a, b)), f"masks differ ({tag})"
 
 
 def test_limits_and_error_paths():
