@@ -82,17 +82,26 @@ class DataParallelAnyRef:
         sl = slice(lo, hi)
         m = self.model
         pick = lambda x: None if x is None else x[sl]
-        (ids, masks, rest), ex = m.generate(
-            clip_images[sl], input_ids[sl], sam_images[sl], sam_resized_sizes[sl], height[sl], width[sl],
-            audios=pick(audios), ref_images=pick(ref_images), max_new_tokens=max_new_tokens,
-            attention_masks=pick(attention_masks), _return_extras=True)
-        if self.world == 1:
-            return ids, masks, rest
         Lout = input_ids.shape[1] + max_new_tokens
+        if hi > lo:
+            (ids, masks, rest), ex = m.generate(
+                clip_images[sl], input_ids[sl], sam_images[sl], sam_resized_sizes[sl], height[sl], width[sl],
+                audios=pick(audios), ref_images=pick(ref_images), max_new_tokens=max_new_tokens,
+                attention_masks=pick(attention_masks), _return_extras=True)
+            if self.world == 1:
+                return ids, masks, rest
+            low, nseg, lens = ex["low_res"], ex["nseg"].to(m.device), ex["out_lens"].to(m.device)
+        else:
+            # a global batch smaller than the world leaves this rank without images: it still takes part in both
+            # collectives (with zero rows), or the other ranks would wait in all_gather forever
+            L = 4 * m.cfg.sam.grid
+            ids = torch.zeros(0, Lout, dtype=torch.long, device=m.device)
+            low = torch.zeros(0, m.max_seg, L, L, dtype=torch.float32, device=m.device)
+            nseg = torch.zeros(0, dtype=torch.int32, device=m.device)
+            lens = torch.zeros(0, dtype=torch.int32, device=m.device)
         idp = torch.zeros(hi - lo, Lout, dtype=torch.long, device=m.device)
         idp[:, : ids.shape[1]] = ids
-        low, nseg, gids, glen = gather_results(ex["low_res"], ex["nseg"].to(m.device), idp,
-                                               ex["out_lens"].to(m.device), n, self.group)
+        low, nseg, gids, glen = gather_results(low, nseg, idp, lens, n, self.group)
         out_ids = gids[:, : int(glen.max())]
         if int(nseg.sum()) == 0:
             return out_ids, None, (None, None, None)

@@ -140,19 +140,45 @@ def weight_shapes(cfg: AnyRefConfig, audio: bool = True) -> Iterator[Tuple[str, 
         yield f"{p}iou_prediction_head.layers.{j}.bias", (a,), "b"
 
 
+def _fan_in(name: str, shape) -> int:
+    """Contraction length of the op a weight feeds (what its output variance scales with)."""
+    if "output_upscaling" in name and len(shape) == 4:      # ConvTranspose2d k2 s2 [C_in, C_out, 2, 2]: one tap per pixel
+        return shape[0]
+    n = 1
+    for d in shape[1:]:
+        n *= d
+    return max(n, 1)
+
+
 def synth_state_dict(cfg: AnyRefConfig, seed: int = 0, scale: float = 0.02, device="cpu",
                      dtype=torch.float32, round_bf16: bool = True, jitter: bool = True,
-                     audio: bool = True) -> Dict[str, torch.Tensor]:
+                     audio: bool = True, init: str = "normal", head_gain: float = 4.0,
+                     mask_gain: float = 4.0) -> Dict[str, torch.Tensor]:
     """Seeded random weights.  With `round_bf16` every value is rounded to bf16 once (and then
     stored in `dtype`), so the fp32 CPU oracle and the bf16 GPU path see identical numbers
-    (SURVEY.md §8d).  `jitter` makes norm gains / biases non-trivial so tests can see them."""
+    (SURVEY.md §8d).  `jitter` makes norm gains / biases non-trivial so tests can see them.
+
+    init="normal": every matrix ~ N(0, scale^2) -- SURVEY.md §8d's throughput workload.  At 7B widths it makes the
+    residual stream tiny and the LM / mask logits nearly flat (range +-0.02), so a parity bound on it is close to
+    vacuous for bf16.
+    init="fan_in": the PARITY workload -- matrices ~ N(0, 1/fan_in) (activations stay O(1) through every layer, as
+    in a trained network), `lm_head` x `head_gain` (peaked next-token logits: std ~ head_gain, like a trained LM's),
+    the last hypernetwork layer x `mask_gain` (mask logits spanning several units; trained ones reach +-20,
+    SURVEY.md §7), embeddings ~ N(0,1), position / rel-pos tables and biases ~ N(0, scale^2), norm gains 1 (+ jitter)."""
+    assert init in ("normal", "fan_in")
     gen = torch.Generator(device=device)
     gen.manual_seed(seed)
     out: Dict[str, torch.Tensor] = {}
     for name, shape, kind in weight_shapes(cfg, audio):
         t = torch.randn(shape, generator=gen, device=device, dtype=torch.float32)
         if kind in ("w", "e"):
-            t *= scale
+            table = len(shape) < 2 or any(k in name for k in ("pos_embed", "position_embedding", "rel_pos", "class_embedding"))
+            if init == "normal" or table:
+                t *= scale
+            elif kind == "w":
+                gain = head_gain if name == "lm_head.weight" else (
+                    mask_gain if "output_hypernetworks_mlps" in name and name.endswith("layers.2.weight") else 1.0)
+                t *= gain / _fan_in(name, shape) ** 0.5
         elif kind == "b":
             t = t * scale if jitter else torch.zeros_like(t)
         elif kind == "g":

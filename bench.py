@@ -39,6 +39,9 @@ from anyref_amd.synth import synth_state_dict  # noqa: E402
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
 PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0       # HBM3E spec peak
+# SAM-H encoder 5.961e12 + CLIP 1.553e11 + projector 2.1e9 + LLM prefill 4.20e12 + decode 1.34e11 +
+# hand-off 3.6e7 + mask decoder 3.6e9 (2 x MAC, S = 320 prompt, 10 new tokens)
+FLOP_PER_IMAGE_C2 = 1.045e13
 
 
 def log(*a):
@@ -251,82 +254,124 @@ def main():
         "roofline": roofline,
         "kernel_breakdown": breakdown,
     }
+    if args.config == "c2":
+        # algorithmic FLOPs of one image (S = 320, T = 10) x images/s over the dense bf16 MFMA peak
+        res["mfma_frac_e2e"] = round(FLOP_PER_IMAGE_C2 * ips / world / (PEAK_BF16_TFLOPS * 1e12), 4)
+        res["flop_per_image"] = FLOP_PER_IMAGE_C2
 
     # ---------------- CPU baseline + parity against it (rank 0, N=1 only) ----------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import anyref_oracle as O
+        from oracle.check import compare_generate, summarize
         # the GPU box gives one GPU a share of 16 host cores (of 256 visible); oversubscribing them
         # makes the fp32 oracle many times slower
         cores = int(os.environ.get("ANYREF_CPU_THREADS", min(16, os.cpu_count() or 1)))
         torch.set_num_threads(cores)
         log("[bench] GPU leg: " + json.dumps({k: res[k] for k in ("value", "ms_per_step", "roofline")}))
-        one = dict(clip=clip[:1], ids=ids[:1], sam=sam[:1], sizes=sizes[:1], H=H[:1], W=W[:1])
+        one = (clip[:1], ids[0], sam[:1], sizes[:1], H[:1], W[:1])
 
-        def gen(m):
-            o, mk, _ = m.generate(one["clip"], one["ids"], one["sam"], one["sizes"], one["H"], one["W"], max_new_tokens=T)
-            torch.cuda.synchronize()
-            return o[0].cpu().tolist(), mk
+        def mode_model(sd_, cfg_, mode_):
+            m_ = AnyRefForCausalLM.from_state_dict(cfg_, sd_, mode=mode_, device=local, max_batch=1, max_seg=2)
+            m_.config.eos_token_id = None
+            return m_
 
-        # parity-mode model first: its greedy ids equal the oracle's, so it names the [SEG] id
-        # (the id emitted at decode step 3) for every leg below
-        parity = {}
-        pm = None
-        if not args.no_parity:
-            pm = AnyRefForCausalLM.from_state_dict(cfg, sd, mode="parity", device=local, max_batch=1, max_seg=2)
-            pm.config.eos_token_id = None
-            p_ids, _ = gen(pm)
-            seg_ref = p_ids[ids.shape[1] + 2]
-            pm.set_seg_token_idx(seg_ref)
-        else:
-            seg_ref = seg_id
-        cfg.seg_token_idx = seg_ref
+        # the oracle's own greedy ids name the [SEG] id (the id emitted at decode step 3)
         t0 = time.time()
         sd_cpu = {k: v.float().cpu() for k, v in sd.items()}
         log(f"[bench] weights on host in {time.time() - t0:.1f}s; timing the CPU oracle on 1 image, {cores} threads")
-        t0 = time.time()
         with torch.no_grad():
-            ref = O.anyref_generate(sd_cpu, cfg, clip[:1].cpu(), [ids[0]], sam[:1].cpu(), sizes[:1], H[:1], W[:1],
-                                    max_new_tokens=T, eos=False, use_cache=True)
-        cpu_s = time.time() - t0
+            img_feats = O.encode_images(sd_cpu, cfg, clip[:1].cpu())
+            first = O.greedy_generate(sd_cpu, cfg, O.splice_embeddings(sd_cpu, cfg, ids[0], img_feats[0]), T, None)[0]
+        cfg.seg_token_idx = int(first[2])          # (that run doubles as the warm-up of the timed ones below)
+
+        def oracle_image(use_cache=True, max_new=T):
+            with torch.no_grad():
+                return O.anyref_generate(sd_cpu, cfg, clip[:1].cpu(), [ids[0]], sam[:1].cpu(), sizes[:1], H[:1], W[:1],
+                                         max_new_tokens=max_new, eos=False, use_cache=use_cache)
+
+        reps = int(os.environ.get("ANYREF_CPU_REPS", 3))
+        times, ref = [], None
+        for _ in range(reps):                      # warm-up, then the median of the timed runs
+            t0 = time.time()
+            ref = oracle_image()
+            times.append(time.time() - t0)
+        cpu_s = sorted(times)[len(times) // 2]
         res["cpu_baseline"] = {"value": round(1.0 / cpu_s, 5), "unit": "images/sec", "cores": cores, "kind": "port",
-                               "sample": f"1 image of the same workload (full forward, fp32, KV cache on): {cpu_s:.1f}s"}
-        want = ref["output_ids"][0].tolist()
-        ref_mask = ref["pred_masks"][0] if ref["pred_masks"] is not None else None
-        if pm is not None:
+                               "sample": f"1 image of the same workload (full forward, fp32, KV cache on): median of {reps} "
+                                         f"runs after a warm-up, {cpu_s:.1f}s ({', '.join(f'{t:.1f}' for t in times)})"}
+        # the reference as written re-runs the whole prefix for every new token (use_cache=False, anyref.py:171):
+        # timed on a bounded sample -- 2 new tokens (2 full-prefix LLM passes + CLIP + SAM + decoder) -- and
+        # extended to T tokens with the measured cost of one full-prefix pass
+        if not os.environ.get("ANYREF_NO_NOCACHE"):
+            with torch.no_grad():
+                emb0 = O.splice_embeddings(sd_cpu, cfg, ids[0], img_feats[0])
+                t0 = time.time()
+                O.llama_layers(sd_cpu, cfg, emb0)
+                pass_s = time.time() - t0
+            t0 = time.time()
+            oracle_image(use_cache=False, max_new=2)
+            two = time.time() - t0
+            nocache_s = two + (T - 2) * pass_s
+            res["cpu_baseline"]["no_cache"] = {
+                "value": round(1.0 / nocache_s, 5), "unit": "images/sec",
+                "sample": f"reference semantics (use_cache=False): 2 new tokens timed ({two:.1f}s) + {T - 2} x one full-prefix "
+                          f"LLM pass ({pass_s:.1f}s each, timed once) = {nocache_s:.1f}s per image"}
+        lm = sd_cpu["lm_head.weight"]
+        n_img = cfg.clip.n_patches
+        parity = {"workload_normal": {}}
+        model.set_seg_token_idx(cfg.seg_token_idx)
+        parity["workload_normal"]["perf"] = summarize([compare_generate(model, ref, *one, T, lm, n_img)])
+        if not args.no_parity:
+            pm = mode_model(sd, cfg, "parity")
             t1 = time.perf_counter()
-            p_ids, p_masks = gen(pm)
-            parity["parity"] = {"greedy_ids_identical": p_ids == want, "ms_per_image": round((time.perf_counter() - t1) * 1e3, 2)}
-            if p_ids == want and p_masks is not None and ref_mask is not None:
-                parity["parity"]["mask_logit_max_abs_err"] = float((p_masks[0].cpu() - ref_mask).abs().max())
-                parity["parity"]["logit_range"] = float(ref_mask.abs().max())
+            parity["workload_normal"]["parity"] = summarize([compare_generate(pm, ref, *one, T, lm, n_img)])
+            parity["workload_normal"]["parity"]["ms_per_image"] = round((time.perf_counter() - t1) * 1e3, 2)
             del pm
             torch.cuda.empty_cache()
-        model.set_seg_token_idx(seg_ref)
-        got, g_masks = gen(model)
-        parity["perf"] = {"greedy_ids_identical": got == want}
-        if got == want and g_masks is not None and ref_mask is not None:
-            parity["perf"]["mask_logit_max_abs_err"] = float((g_masks[0].cpu() - ref_mask).abs().max())
-        else:
-            # bf16 flipped a near-tied argmax: say where and how tied, then isolate the NUMERICAL error by
-            # teacher-forcing the oracle's ids through the bf16 path (anyref.py:239-430 semantics)
-            L0 = ids.shape[1]
-            k = next((i for i in range(min(len(got), len(want))) if got[i] != want[i]), len(want) - 1)
-            parity["perf"]["first_divergence_new_token"] = k - L0
+        parity["workload_normal"]["note"] = ("the timed workload (SURVEY.md §8d, every matrix N(0,0.02^2)): logits are nearly "
+                                             "flat, so read the errors relative to logit_range")
+        # ---- the PARITY workload: fan-in-scaled weights (O(1) activations, peaked LM logits, mask logits of several
+        # units; anyref_amd.synth init="fan_in"), several prompts over one image -> ids-match rate + relative error
+        n_prompts = int(os.environ.get("ANYREF_PARITY_PROMPTS", 4))
+        if not args.no_parity and args.config == "c2" and n_prompts > 0:
+            del sd_cpu, ref             # 27 GB of host fp32 weights: make room for the second workload's
+            t0 = time.time()
+            sd2 = synth_state_dict(cfg, seed=0, device=dev, dtype=torch.bfloat16, init="fan_in")
+            sd2_cpu = {k: v.float().cpu() for k, v in sd2.items()}
+            g2 = torch.Generator().manual_seed(7)
+            prompts = [torch.cat([torch.tensor([1, IMAGE_TOKEN_INDEX]), torch.randint(3, 32000, (63,), generator=g2)])
+                       for _ in range(n_prompts)]
+            clip1, sam1 = clip[:1].cpu(), sam[:1].cpu()
             with torch.no_grad():
-                hrow = ref["hidden"][0][k - 1 + cfg.clip.n_patches - 1]
-                lg = torch.nn.functional.linear(hrow, sd_cpu["lm_head.weight"])
-                top2 = torch.topk(lg, 2).values
-            parity["perf"]["oracle_top2_logit_gap_there"] = float(top2[0] - top2[1])
-            parity["perf"]["oracle_logit_std"] = float(lg.std())
-            full = ref["output_ids"][0]
-            if ref_mask is not None:
-                out = model.model_forward_new(clip[:1], sam[:1], full[None], full[None].clone(), None, sizes[:1], None,
-                                              H[:1], W[:1], _return_extras=True)
-                if "pred_masks" in out:
-                    parity["perf"]["teacher_forced_mask_logit_max_abs_err"] = float(
-                        (out["pred_masks"][0].cpu() - ref_mask).abs().max())
-        if ref_mask is not None:
-            parity["logit_range"] = float(ref_mask.abs().max())
+                feats = O.encode_images(sd2_cpu, cfg, clip1)
+                outs = [O.greedy_generate(sd2_cpu, cfg, O.splice_embeddings(sd2_cpu, cfg, p_, feats[0]), T, None)
+                        for p_ in prompts]
+                cfg.seg_token_idx = int(outs[0][0][2])
+                fulls = [torch.cat([p_, torch.tensor(o[0])]) for p_, o in zip(prompts, outs)]
+                tail = O.generate_tail(sd2_cpu, cfg, [fulls[0]], [len(prompts[0])], [outs[0][1]], None, sam1, sizes[:1],
+                                       H[:1], W[:1])
+            refs = [dict(output_ids=[f], hidden=[o[1]], pred_masks=tail["pred_masks"] if i == 0 else None)
+                    for i, (f, o) in enumerate(zip(fulls, outs))]
+            log(f"[bench] parity workload: CPU oracle on {n_prompts} prompts (1 with masks) in {time.time() - t0:.0f}s")
+            lm2 = sd2_cpu["lm_head.weight"]
+            parity["workload_fan_in"] = {}
+            for mode_ in ("parity", "perf"):
+                m2 = mode_model(sd2, cfg, mode_)
+                rows = [compare_generate(m2, refs[i], clip[:1], prompts[i], sam[:1], sizes[:1], H[:1], W[:1], T, lm2, n_img)
+                        for i in range(n_prompts)]
+                parity["workload_fan_in"][mode_] = summarize(rows)
+                del m2
+                torch.cuda.empty_cache()
+            parity["workload_fan_in"]["note"] = ("fan-in-scaled weights: hidden states O(1), LM logit std ~4, mask logits of "
+                                                 "several units; a flipped greedy id is followed by a teacher-forced comparison")
+        # the headline parity numbers (north_star: identical greedy ids, mask logits within 1e-3) per arithmetic mode,
+        # taken from the workload where they bite
+        src = parity.get("workload_fan_in", parity["workload_normal"])
+        for mode_ in ("parity", "perf"):
+            if mode_ in src:
+                parity[mode_] = {k: src[mode_][k] for k in ("ids_match_rate", "mask_logit_max_abs_err", "mask_logit_rel_err",
+                                                             "logit_range", "first_divergence_new_token") if k in src[mode_]}
+                parity[mode_]["rel_err"] = src[mode_].get("mask_logit_rel_err")
         res["parity"] = parity
     if rank == 0:
         print(json.dumps(res), flush=True)

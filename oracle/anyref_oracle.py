@@ -520,7 +520,7 @@ def splice_ref_rows(f: Optional[torch.Tensor], n_slots: int):
 
 def generate_tail(w: W, cfg, output_ids: List[torch.Tensor], prompt_lens: Sequence[int],
                   hiddens: List[torch.Tensor], attns: Optional[List[Optional[torch.Tensor]]],
-                  sam_images, sam_resized_sizes, height, width):
+                  sam_images, sam_resized_sizes, height, width, image_embeddings=None):
     """Everything `generate` does AFTER `super().generate` returns (anyref.py:718-822), for per-sample LLM
     outputs: `output_ids[b]` [L_b+T_b], `hiddens[b]` = `outputs.hidden_states[-1][b]` [L_b+T_b-1+255, H],
     `attns[b]` = `outputs.attentions[-1][b]` [heads,S,S] (or its head mean [S,S]).
@@ -551,7 +551,8 @@ def generate_tail(w: W, cfg, output_ids: List[torch.Tensor], prompt_lens: Sequen
     if not seg_hidden:                                                     # :729-730
         return dict(pred_masks=None, low_res=None, pred_embeddings=None)
     pred = text_hidden_fc(w, torch.stack(seg_hidden))                      # :770
-    img_emb = sam_image_encoder(w, cfg, sam_images)                        # :793
+    # :793 (`image_embeddings`: a caller that runs several prompts over one image may pass the encoder output in)
+    img_emb = sam_image_encoder(w, cfg, sam_images) if image_embeddings is None else image_embeddings
     seg_batch_t = torch.tensor(seg_batch)
     masks, lows = [], []
     for b in range(B):                                                     # :797-819

@@ -121,6 +121,76 @@ def test_dp_gather_gloo_world2(tmp_path, n):
         assert p.returncode == 0 and "OK" in out, out
 
 
+_DP_WORKER = r'''
+import os, sys, types, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from anyref_amd.parallel import DataParallelAnyRef, shard_range
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:" + sys.argv[2], rank=rank, world_size=world)
+n, T, L, G = int(sys.argv[3]), 3, 6, 4
+
+class FakeModel:
+    """per-GPU model stand-in with the mirror's generate(..., _return_extras=True) contract, CPU tensors"""
+    device = torch.device("cpu")
+    max_seg = 2
+    cfg = types.SimpleNamespace(sam=types.SimpleNamespace(grid=G))
+    calls = 0
+    def generate(self, clip, ids, sam, sizes, H, W, audios=None, ref_images=None, max_new_tokens=128,
+                 attention_masks=None, _return_extras=False):
+        FakeModel.calls += 1
+        b = clip.shape[0]
+        assert b > 0, "an empty shard must not reach the model"
+        key = clip[:, 0, 0, 0].long()                      # the global image index planted by the test
+        out = torch.cat([ids, key[:, None] * 10 + torch.arange(max_new_tokens)[None]], 1)
+        nseg = (key % 3).int()                              # 0, 1 or 2 masks per image
+        low = key.float()[:, None, None, None] + torch.arange(self.max_seg).float()[None, :, None, None] * 0.5 \
+            + torch.zeros(b, self.max_seg, 4 * G, 4 * G)
+        masks = [low[i, : int(nseg[i])] for i in range(b)]
+        return (out, masks, (None, None, None)), dict(low_res=low, nseg=nseg, out_lens=torch.full((b,), L + max_new_tokens).int())
+    def postprocess(self, low, resized, orig):
+        return low + 100.0                                  # marks "re-created from the gathered low-res logits"
+
+clip = torch.zeros(n, 3, 2, 2); clip[:, 0, 0, 0] = torch.arange(n).float()
+ids = torch.arange(n * L).reshape(n, L)
+dp = DataParallelAnyRef(FakeModel())
+out_ids, masks, rest = dp.generate(clip, ids, torch.zeros(n, 3, 2, 2), [(8, 8)] * n, [8] * n, [8] * n, max_new_tokens=T)
+lo, hi = shard_range(n, rank, world)
+assert FakeModel.calls == (1 if hi > lo else 0)
+assert rest == (None, None, None) and out_ids.shape == (n, L + T)
+for b in range(n):
+    assert out_ids[b, :L].tolist() == ids[b].tolist() and out_ids[b, L:].tolist() == [b * 10 + t for t in range(T)]
+if all(b % 3 == 0 for b in range(n)):
+    assert masks is None
+else:
+    for b in range(n):
+        k = b % 3
+        assert masks[b].shape[0] == k
+        for j in range(k):
+            assert float(masks[b][j, 0, 0]) == b + 0.5 * j + 100.0
+dist.barrier()
+dist.destroy_process_group()
+print("OK", rank)
+'''
+
+
+@pytest.mark.parametrize("n", [1, 2, 5])
+def test_data_parallel_wrapper_gloo_world2(tmp_path, n):
+    """`DataParallelAnyRef.generate` itself over gloo with 2 ranks: a global batch smaller than the world (a rank
+    with NO images still joins both collectives), an even split, and a ragged tail; every rank returns the global
+    result in order, masks re-created from the gathered low-res logits."""
+    script = tmp_path / "dp.py"
+    script.write_text(_DP_WORKER)
+    port = str(31500 + os.getpid() % 2000 + n)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT, port, str(n)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    for p in procs:
+        out, _ = p.communicate(timeout=120)
+        assert p.returncode == 0 and "OK" in out, out
+
+
 def test_oracle_eval_steps_known_answers():
     """SURVEY.md §8 f-1 / f-2 restatements against hand-computed values (utils/utils.py:79-91,
     utils/refer_seg.py:560-570)."""

@@ -1,0 +1,99 @@
+"""BASELINE.json configs[1] at FULL size inside `-m gpu`: LLaVA-7B-shaped LLaMA (32 x 4096 / 11008) + CLIP ViT-L/14
+(23 layers run) + SAM-H (32 x 1280, 1024^2) + mask decoder, the bench inputs (S = 320 prompt, 10 new tokens), both
+arithmetic modes through the C-ABI against the CPU fp32 oracle on the same (image, instruction) pairs.
+
+Two seeded workloads:
+  * "normal"  SURVEY.md §8d's throughput workload, every matrix N(0, 0.02^2) -- what bench.py times.  Its residual
+              stream is tiny and its logits nearly flat (mask logits +-0.02, LM top-2 gap ~0.04 at sigma 1.3), so its
+              1e-3 absolute bound cannot bite for bf16: kept for continuity with bench.py, judged RELATIVE to range.
+  * "fan_in"  the parity workload (anyref_amd.synth, init="fan_in"): O(1) activations, peaked LM logits (sigma ~4),
+              mask logits of several units -- where a numerical error shows.
+north_star bar -- identical greedy ids and mask logits within 1e-3 -- is asserted for parity mode on both.  For the
+bf16 perf mode the test asserts measured-error x 2 bounds (relative to the logit range) and reports the ids-match
+rate over 8 prompts; a flipped greedy id is followed by a teacher-forced comparison, never skipped.
+"""
+import gc
+import json
+import os
+import time
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from anyref_amd.config import config_7b, IMAGE_TOKEN_INDEX  # noqa: E402
+from anyref_amd.synth import synth_state_dict  # noqa: E402
+from oracle import anyref_oracle as O  # noqa: E402
+from oracle.check import compare_generate, summarize  # noqa: E402
+
+T_NEW = 10
+N_PROMPTS = 8          # ids-match rate is taken over these; the first N_MASKS also compare mask logits
+N_MASKS = 2
+# perf-mode bounds = 2 x the error measured on MI355X (gpurun_out/r2_t3.log), relative to the range
+PERF_REL_BOUND = {"normal": 0.026, "fan_in": 0.005}      # measured 1.3e-2 (teacher-forced) / 2.4e-3
+
+
+def _inputs(cfg, n, seed):
+    g = torch.Generator().manual_seed(seed)
+    clip = torch.randn(1, 3, 224, 224, generator=g)
+    sam = torch.randn(1, 3, 1024, 1024, generator=g)
+    hi = min(32000, cfg.llm.vocab - 8)
+    ids = [torch.cat([torch.tensor([1, IMAGE_TOKEN_INDEX]), torch.randint(3, hi, (63,), generator=g)]) for _ in range(n)]
+    return clip, sam, ids
+
+
+@pytest.mark.parametrize("init", ["fan_in", "normal"])
+def test_c2_full_size_parity_and_perf(init):
+    from anyref_amd.model import AnyRefForCausalLM
+    cores = int(os.environ.get("ANYREF_CPU_THREADS", min(16, os.cpu_count() or 1)))
+    torch.set_num_threads(cores)
+    cfg = config_7b()
+    cfg.llm.max_seq = 512
+    t0 = time.time()
+    sd = synth_state_dict(cfg, seed=0, device="cuda", dtype=torch.bfloat16, init=init)
+    clip, sam, ids = _inputs(cfg, N_PROMPTS, seed=1)
+    sizes, H, W = [(1024, 1024)], [1024], [1024]
+    sd_cpu = {k: v.float().cpu() for k, v in sd.items()}
+    print(f"[{init}] weights ready in {time.time() - t0:.0f}s", flush=True)
+
+    # the oracle: the [SEG] id is the id its own greedy decode emits at step 3 of prompt 0
+    with torch.no_grad():
+        img_feats = O.encode_images(sd_cpu, cfg, clip)
+        first = O.greedy_generate(sd_cpu, cfg, O.splice_embeddings(sd_cpu, cfg, ids[0], img_feats[0]), T_NEW, None)[0]
+    cfg.seg_token_idx = int(first[2])
+    refs = []
+    t0 = time.time()
+    with torch.no_grad():
+        img_emb = O.sam_image_encoder(sd_cpu, cfg, sam)        # prompt-independent: one SAM-H forward for all prompts
+        for i in range(N_PROMPTS):
+            emb = O.splice_embeddings(sd_cpu, cfg, ids[i], img_feats[0])
+            new_ids, hidden, _ = O.greedy_generate(sd_cpu, cfg, emb, T_NEW, None)
+            full = torch.cat([ids[i], torch.tensor(new_ids)])
+            r = dict(output_ids=[full], hidden=[hidden], pred_masks=None)
+            if i < N_MASKS:
+                r["pred_masks"] = O.generate_tail(sd_cpu, cfg, [full], [len(ids[i])], [hidden], None, sam, sizes, H, W,
+                                                  image_embeddings=img_emb)["pred_masks"]
+            refs.append(r)
+    print(f"[{init}] CPU oracle: {N_PROMPTS} prompts ({N_MASKS} with masks) in {time.time() - t0:.0f}s on {cores} threads",
+          flush=True)
+    assert refs[0]["pred_masks"] is not None
+
+    report = {}
+    for mode in ("parity", "perf"):
+        m = AnyRefForCausalLM.from_state_dict(cfg, sd, mode=mode, max_batch=1, max_seg=4)
+        m.config.eos_token_id = None
+        rows = [compare_generate(m, refs[i], clip, ids[i], sam, sizes, H, W, T_NEW, sd_cpu["lm_head.weight"],
+                                 cfg.clip.n_patches) for i in range(N_PROMPTS)]
+        report[mode] = summarize(rows)
+        del m
+        gc.collect()
+        torch.cuda.empty_cache()
+    print(f"C2_FULL[{init}] " + json.dumps(report), flush=True)
+    p, q = report["parity"], report["perf"]
+    # north_star, parity mode: identical greedy ids on every prompt, mask logits within 1e-3
+    assert p["ids_match_rate"] == 1.0, p
+    assert p["masks_compared"] >= 1 and p["mask_logit_max_abs_err"] <= 1e-3, p
+    # perf (bf16) mode: every prompt compared (teacher-forced after a flipped id), error bounded relative to range
+    assert q["masks_compared"] == p["masks_compared"], q
+    assert q["mask_logit_rel_err"] <= PERF_REL_BOUND[init], q

@@ -13,8 +13,13 @@ from anyref_amd.config import config_tiny, IMAGE_TOKEN_INDEX, AUDIO_REF_INDEX  #
 from anyref_amd.synth import synth_state_dict  # noqa: E402
 from oracle import anyref_oracle as O  # noqa: E402
 
+from oracle.check import compare_generate  # noqa: E402
+
 MASK_TOL = 1e-3          # north_star bound, parity mode
-PERF_MASK_TOL = 5e-2     # bf16 operands; logits of the tiny random model are O(1)
+# bf16 perf mode, relative to the range of the compared quantity: 2 x the worst error measured on MI355X over these
+# configurations (mask logits 2.3e-3 on +-0.56 = 0.41 %; hidden states 2.6e-2 on a scale of 4.56 = 0.58 %) -- DESIGN.md §3
+PERF_MASK_REL = 0.009
+PERF_HIDDEN_REL = 0.012
 
 
 def make_inputs(cfg, B, seed, L=16, audio=False):
@@ -68,16 +73,20 @@ def test_generate_matches_oracle(mode, window, sam_dim, sam_heads):
     m.config.eos_token_id = None
     (out_ids, masks, rest), ex = m.generate(clip, ids[0][None], sam, sizes, H, W, max_new_tokens=6, _return_extras=True)
     assert rest == (None, None, None)
+    same = out_ids[0].cpu().tolist() == ref["output_ids"][0].tolist()
     if mode == "parity":
-        assert out_ids[0].cpu().tolist() == ref["output_ids"][0].tolist(), "greedy ids differ"
+        assert same, "greedy ids differ"
     n = ref["hidden"][0].shape[0]
-    herr = (ex["hidden"][0, :n].cpu() - ref["hidden"][0]).abs().max().item()
-    assert herr < (2e-4 if mode == "parity" else 0.15), f"hidden err {herr}"
-    if out_ids[0].cpu().tolist() == ref["output_ids"][0].tolist():
-        assert masks[0].shape == ref["pred_masks"][0].shape
-        err = (masks[0].cpu() - ref["pred_masks"][0]).abs().max().item()
-        print(f"[{mode}] mask-logit max-abs-err {err:.3e} (range ±{ref['pred_masks'][0].abs().max():.2f})")
-        assert err <= (MASK_TOL if mode == "parity" else PERF_MASK_TOL)
+    if same:
+        herr = (ex["hidden"][0, :n].cpu() - ref["hidden"][0]).abs().max().item()
+        hscale = ref["hidden"][0].abs().max().item()
+        print(f"[{mode}] hidden max-abs-err {herr:.3e} (scale {hscale:.2f})")
+        assert herr < (2e-4 if mode == "parity" else PERF_HIDDEN_REL * hscale), f"hidden err {herr}"
+    # masks are ALWAYS compared: after a flipped greedy id (bf16), the oracle's ids are teacher-forced through the
+    # backend (anyref.py:239-430 semantics) so the numerical error of the path is still measured
+    r = compare_generate(m, ref, clip, ids[0], sam, sizes, H, W, 6, sd["lm_head.weight"], cfg.clip.n_patches)
+    print(f"[{mode}] " + " ".join(f"{k}={v:.3e}" if isinstance(v, float) else f"{k}={v}" for k, v in r.items()))
+    assert r["mask_logit_max_abs_err"] <= (MASK_TOL if mode == "parity" else PERF_MASK_REL * r["logit_range"]), r
 
 
 def test_generate_batch_audio_eos_and_noseg():
@@ -241,14 +250,17 @@ def test_decode_mfma_path_batch_gt4(mode):
                                      _return_extras=True)
         n = len(ids[b]) + cfg.clip.n_patches - 1 + 7
         d = (ex6["hidden"][b, :n] - ex1["hidden"][0, :n]).abs().max().item()
-        assert d < 0.1, f"row {b}: batched (MFMA) vs single (GEMV) hidden differ by {d}"
+        print(f"[{mode}] B=6 row {b}: batched (MFMA) vs single (GEMV) hidden differ by {d:.3e}")
+        assert d < 0.025, f"row {b}: batched (MFMA) vs single (GEMV) hidden differ by {d}"   # 2 x measured 1.2e-2 (fp8w)
         if b < 2:
             with torch.no_grad():
                 ref = O.anyref_generate(sd_ref, cfg, clip[b:b + 1], [ids[b]], sam[b:b + 1], sizes[:1], H[:1], W[:1],
                                         max_new_tokens=8, eos=False)
             if o6[b, : len(ids[b]) + 8].cpu().tolist() == ref["output_ids"][0].tolist():
                 herr = (ex6["hidden"][b, :n].cpu() - ref["hidden"][0][:n]).abs().max().item()
-                assert herr < 0.15, f"row {b}: hidden err vs oracle {herr}"
+                hscale = ref["hidden"][0].abs().max().item()
+                print(f"[{mode}] B=6 row {b}: hidden max-abs-err {herr:.3e} (scale {hscale:.2f})")
+                assert herr < PERF_HIDDEN_REL * hscale, f"row {b}: hidden err vs oracle {herr}"
 
 
 @pytest.mark.parametrize("mode", ["parity", "perf"])
@@ -282,8 +294,9 @@ def test_generate_llama7b_shaped_layers_vs_oracle(mode):
     got, want = ex["hidden"][0, :n].cpu(), ref["hidden"][0]
     scale = want.abs().max().item()
     perr = (got[:320] - want[:320]).abs().max().item()
-    assert perr < (2e-4 if mode == "parity" else 0.05) * max(1.0, scale), f"prefill hidden err {perr} (scale {scale})"
+    print(f"[{mode}] prefill hidden max-abs-err {perr:.3e} (scale {scale:.2f}), ids identical: {same}")
+    assert perr < (2e-4 if mode == "parity" else PERF_HIDDEN_REL) * max(1.0, scale), f"prefill hidden err {perr} (scale {scale})"
     if same:   # the decode rows are comparable only along the same token path
         derr = (got[320:] - want[320:]).abs().max().item()
-        assert derr < (2e-4 if mode == "parity" else 0.05) * max(1.0, scale), f"decode hidden err {derr} (scale {scale})"
+        assert derr < (2e-4 if mode == "parity" else PERF_HIDDEN_REL) * max(1.0, scale), f"decode hidden err {derr} (scale {scale})"
         print(f"[{mode}] prefill / decode hidden max-abs-err {perr:.3e} / {derr:.3e} (scale {scale:.2f})")

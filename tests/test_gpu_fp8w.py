@@ -107,11 +107,15 @@ def test_generate_fp8w_matches_oracle_on_dequantised_weights():
     m.config.eos_token_id = None
     (out_ids, masks, _), ex = m.generate(clip, ids[0][None], sam, sizes, H, W, max_new_tokens=6, _return_extras=True)
     n = ref["hidden"][0].shape[0]
-    herr = (ex["hidden"][0, :n].cpu() - ref["hidden"][0]).abs().max().item()
-    assert herr < 0.15, f"hidden err {herr}"                      # the bf16 perf-mode bound (test_gpu_e2e)
+    hscale = ref["hidden"][0].abs().max().item()
     if out_ids[0].cpu().tolist() == ref["output_ids"][0].tolist():
-        err = (masks[0].cpu() - ref["pred_masks"][0]).abs().max().item()
-        assert err <= 5e-2, err
+        herr = (ex["hidden"][0, :n].cpu() - ref["hidden"][0]).abs().max().item()
+        print(f"[perf_fp8w] hidden max-abs-err {herr:.3e} (scale {hscale:.2f})")
+        assert herr < 0.012 * hscale, f"hidden err {herr}"         # 2 x measured (2.4e-2 on 4.57), = test_gpu_e2e.PERF_HIDDEN_REL
+    from oracle.check import compare_generate                      # masks always compared (teacher-forced after a flip)
+    r = compare_generate(m, ref, clip, ids[0], sam, sizes, H, W, 6, sd_dq["lm_head.weight"], cfg.clip.n_patches)
+    print("[perf_fp8w] " + " ".join(f"{k}={v:.3e}" if isinstance(v, float) else f"{k}={v}" for k, v in r.items()))
+    assert r["mask_logit_max_abs_err"] <= 0.009 * r["logit_range"], r    # 2 x measured (3.5e-3 relative)
     # the fp8 model is NOT the bf16 model: same call on the original weights differs
     m2 = AnyRefForCausalLM.from_state_dict(cfg, {k: v.cuda() for k, v in sd.items()}, mode="perf", max_batch=1, max_seg=4)
     m2.config.eos_token_id = None

@@ -18,8 +18,8 @@ from anyref_amd.synth import synth_state_dict  # noqa: E402
 
 GLUE = np.load(os.path.join(HERE, "golden", "glue_anyref.npz"))
 # the hand-off and the whole mask decoder are f32 in both modes; only the SAM image encoder differs (bf16 in perf):
-# measured 2.1e-6 (parity) / 1.6e-3 (perf) on logits of range +-0.7 -> bound = 1e-3 north-star / 2x measured
-TOL = {"parity": 1e-3, "perf": 4e-3}
+# measured 8e-7 (parity) / 1.6e-3 (perf) on MI355X -> bound = the 1e-3 north-star bar / 2 x measured
+TOL = {"parity": 1e-3, "perf": 3.2e-3}
 
 
 def _model(c, mode, seg_list=False):

@@ -16,9 +16,10 @@ import make_golden as mg  # noqa: E402
 from anyref_amd.synth import synth_state_dict  # noqa: E402
 from oracle import anyref_oracle as O  # noqa: E402
 
-# parity mode must sit well inside the 1e-3 logit bound; perf mode (bf16 operands) is reported
-# against a looser stage bound and quantified end-to-end in test_gpu_e2e.py
-TOL = {"parity": 2e-4, "perf": 6e-2}
+# parity mode must sit well inside the 1e-3 logit bound.  perf mode (bf16 operands): bound = 2 x the worst stage error
+# measured on MI355X, relative to the stage output's scale (5.4e-3: a 2-layer LLaMA's hidden states; SAM-H-width
+# encoder 3.8e-3; CLIP tower 3e-3 -- gpurun_out/r2_t3.log); quantified end to end in test_gpu_e2e.py / test_gpu_c2_full.py
+TOL = {"parity": 2e-4, "perf": 1.1e-2}
 
 
 def close(got, ref, tol, what=""):
@@ -26,6 +27,7 @@ def close(got, ref, tol, what=""):
     ref = ref.detach().float().cpu() if isinstance(ref, torch.Tensor) else torch.from_numpy(np.asarray(ref))
     err = (got - ref).abs().max().item()
     scale = max(1.0, ref.abs().max().item())
+    print(f"    {what}: err/scale {err / scale:.3e} (tol {tol:g})")
     assert np.isfinite(err) and err <= tol * scale, f"{what}: max abs err {err:.3e}, scale {scale:.3e}, tol {tol}"
     return err
 
