@@ -1009,6 +1009,105 @@ void launch_sam_preprocess(const uint8_t* img, int h, int w, int S, const float*
                      mean[0], mean[1], mean[2], std_[0], std_[1], std_[2], out);
 }
 
+// f-1: `ResizeLongestSide.apply_image` (segment_anything/utils/transforms.py:27-34) = torchvision `resize` of a PIL
+// image = Pillow `Image.resize(..., BILINEAR)`, and the bicubic shortest-edge resize inside `CLIPImageProcessor`
+// (utils/refer_seg.py:578-580).  Pillow (un-vendored dependency; algorithm of src/libImaging/Resample.c, 12.2.0
+// here) resamples 8-bit images separably in FIXED POINT: per output index a window [xmin, xmin + n) of input pixels
+// and int32 coefficients round(k * 2^22) (normalised filter taps; the support widens with the downscale factor =
+// antialiasing); out = clip8((2^21 + sum pixel * coeff) >> 22); horizontal pass first, its uint8 result feeds the
+// vertical pass.  The (tiny) coefficient tables are built on the host in double exactly as precompute_coeffs /
+// normalize_coeffs_8bpc do (anyref_amd/preprocess.py); the two integer passes below are bit-exact.
+__global__ __launch_bounds__(256) void resample_h_u8_kernel(const uint8_t* __restrict__ in, int H, int W, int C,
+                                                            uint8_t* __restrict__ out, int ow,
+                                                            const int* __restrict__ bounds, const int* __restrict__ kk,
+                                                            int ksize) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)H * ow * C) return;
+  const int c = (int)(i % C), xx = (int)((i / C) % ow);
+  const int64_t y = i / ((int64_t)C * ow);
+  const int xmin = bounds[2 * xx], n = bounds[2 * xx + 1];
+  const int* k = kk + (int64_t)xx * ksize;
+  const uint8_t* row = in + (y * W + xmin) * C + c;
+  int ss = 1 << 21;
+  for (int x = 0; x < n; ++x) ss += (int)row[(int64_t)x * C] * k[x];
+  ss >>= 22;
+  out[i] = (uint8_t)(ss < 0 ? 0 : (ss > 255 ? 255 : ss));
+}
+__global__ __launch_bounds__(256) void resample_v_u8_kernel(const uint8_t* __restrict__ in, int H, int64_t WC,
+                                                            uint8_t* __restrict__ out, int oh,
+                                                            const int* __restrict__ bounds, const int* __restrict__ kk,
+                                                            int ksize) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)oh * WC) return;
+  const int64_t col = i % WC;
+  const int yy = (int)(i / WC);
+  const int ymin = bounds[2 * yy], n = bounds[2 * yy + 1];
+  const int* k = kk + (int64_t)yy * ksize;
+  const uint8_t* p = in + (int64_t)ymin * WC + col;
+  int ss = 1 << 21;
+  for (int y = 0; y < n; ++y) ss += (int)p[(int64_t)y * WC] * k[y];
+  ss >>= 22;
+  out[i] = (uint8_t)(ss < 0 ? 0 : (ss > 255 ? 255 : ss));
+}
+void launch_pil_resample_u8(const uint8_t* in, int H, int W, int C, uint8_t* tmp, uint8_t* out, int ow, int oh,
+                            const int* xbounds, const int* xk, int kx, const int* ybounds, const int* yk, int ky,
+                            hipStream_t s) {
+  if (H <= 0 || W <= 0 || C <= 0 || ow <= 0 || oh <= 0) throw std::runtime_error("pil_resample: empty image");
+  // Pillow skips a pass whose size does not change (ImagingResample: need_horizontal / need_vertical)
+  const bool need_h = ow != W, need_v = oh != H;
+  const uint8_t* src = in;
+  if (need_h) {
+    if (!xbounds || !xk || kx <= 0) throw std::runtime_error("pil_resample: horizontal pass needs its coefficient table");
+    uint8_t* dst = need_v ? tmp : out;
+    if (!dst) throw std::runtime_error("pil_resample: two passes need the [H, ow, C] scratch image");
+    hipLaunchKernelGGL(resample_h_u8_kernel, dim3((unsigned)cdiv64((int64_t)H * ow * C, 256)), dim3(256), 0, s, src, H, W,
+                       C, dst, ow, xbounds, xk, kx);
+    src = dst;
+  }
+  if (need_v) {
+    if (!ybounds || !yk || ky <= 0) throw std::runtime_error("pil_resample: vertical pass needs its coefficient table");
+    hipLaunchKernelGGL(resample_v_u8_kernel, dim3((unsigned)cdiv64((int64_t)oh * ow * C, 256)), dim3(256), 0, s, src, H,
+                       (int64_t)ow * C, out, oh, ybounds, yk, ky);
+  } else if (!need_h) {
+    HIP_TRY(hipMemcpyAsync(out, in, (size_t)H * W * C, hipMemcpyDeviceToDevice, s));
+  }
+}
+
+// f-1: the rest of the CLIP input path (utils/refer_seg.py:578-587) on the resized uint8 HWC image: rescale by
+// 1/255 in DOUBLE then to f32, (x - mean) / std in f32 -- the image processor's arithmetic, bit for bit -- and
+// `F.interpolate(size=(S, S), mode="bilinear", align_corners=False)` (PyTorch upsample_bilinear2d, bil_idx above).
+// Rows [y0, y0 + h) x columns [x0, x0 + w) of the [ih, iw, 3] image are the source (the centre crop when enabled).
+__device__ inline float clip_px(const uint8_t* __restrict__ img, int iw, int y, int x, int c, float m, float sd) {
+  const float v = (float)((double)img[((int64_t)y * iw + x) * 3 + c] * (1.0 / 255.0));
+  return (v - m) / sd;
+}
+__global__ __launch_bounds__(256) void clip_finish_kernel(const uint8_t* __restrict__ img, int iw, int y0, int x0,
+                                                          int h, int w, int S, float m0, float m1, float m2, float s0,
+                                                          float s1, float s2, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)3 * S * S) return;
+  const int c = (int)(i / ((int64_t)S * S)), Y = (int)((i / S) % S), X = (int)(i % S);
+  const float m = c == 0 ? m0 : (c == 1 ? m1 : m2), sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
+  if (h == S && w == S) {  // interpolate to the same size is the identity in PyTorch as well
+    out[i] = clip_px(img, iw, y0 + Y, x0 + X, c, m, sd);
+    return;
+  }
+  int ya, yb, xa, xb;
+  float ly, lx;
+  bil_idx(Y, (float)h / (float)S, h, ya, yb, ly);
+  bil_idx(X, (float)w / (float)S, w, xa, xb, lx);
+  const float a = clip_px(img, iw, y0 + ya, x0 + xa, c, m, sd), b = clip_px(img, iw, y0 + ya, x0 + xb, c, m, sd);
+  const float cc = clip_px(img, iw, y0 + yb, x0 + xa, c, m, sd), d = clip_px(img, iw, y0 + yb, x0 + xb, c, m, sd);
+  out[i] = (1.f - ly) * ((1.f - lx) * a + lx * b) + ly * ((1.f - lx) * cc + lx * d);
+}
+void launch_clip_finish(const uint8_t* img, int ih, int iw, int y0, int x0, int h, int w, int S, const float* mean,
+                        const float* std_, float* out, hipStream_t s) {
+  if (h <= 0 || w <= 0 || y0 < 0 || x0 < 0 || y0 + h > ih || x0 + w > iw || S <= 0)
+    throw std::runtime_error("clip_finish: source window outside the image");
+  hipLaunchKernelGGL(clip_finish_kernel, dim3((unsigned)cdiv64((int64_t)3 * S * S, 256)), dim3(256), 0, s, img, iw, y0, x0,
+                     h, w, S, mean[0], mean[1], mean[2], std_[0], std_[1], std_[2], out);
+}
+
 // rows[i] of dst <- bias (SAM window layers: q/k/v of a zero-padded token is exactly the bias)
 template <typename T>
 __global__ __launch_bounds__(256) void fill_rows_bias_kernel(T* __restrict__ dst, int ld, const int* __restrict__ rows,

@@ -141,4 +141,15 @@ int anyref_op_sam_preprocess(void* stream, const uint8_t* img, int h, int w, int
                              const float* std3, float* out) {
   OP_GUARD(launch_sam_preprocess(img, h, w, S, mean3, std3, out, (hipStream_t)stream));
 }
+
+int anyref_op_pil_resample_u8(void* stream, const uint8_t* in, int H, int W, int C, uint8_t* tmp, uint8_t* out, int ow,
+                              int oh, const int32_t* xbounds, const int32_t* xk, int kx, const int32_t* ybounds,
+                              const int32_t* yk, int ky) {
+  OP_GUARD(launch_pil_resample_u8(in, H, W, C, tmp, out, ow, oh, xbounds, xk, kx, ybounds, yk, ky, (hipStream_t)stream));
+}
+
+int anyref_op_clip_finish(void* stream, const uint8_t* img, int ih, int iw, int y0, int x0, int h, int w, int S,
+                          const float* mean3, const float* std3, float* out) {
+  OP_GUARD(launch_clip_finish(img, ih, iw, y0, x0, h, w, S, mean3, std3, out, (hipStream_t)stream));
+}
 }

@@ -55,6 +55,21 @@ int anyref_op_avs_counts(void* stream, const float* logits, const uint8_t* targe
  * std3 are HOST pointers. */
 int anyref_op_sam_preprocess(void* stream, const uint8_t* img, int h, int w, int S, const float* mean3,
                              const float* std3, float* out);
+/* SURVEY.md §8 f-1, replaces `ResizeLongestSide.apply_image` (segment_anything/utils/transforms.py:27-34) and the
+ * bicubic resize inside `CLIPImageProcessor.preprocess` (utils/refer_seg.py:578-580): Pillow's 8-bit separable
+ * fixed-point resampling, bit-exact.  in u8 [H, W, C] dev -> out u8 [oh, ow, C] dev; tmp u8 [H, ow, C] dev scratch
+ * (needed when both sizes change).  Coefficient tables (device, int32; built on the host as Pillow's
+ * precompute_coeffs + normalize_coeffs_8bpc do): xbounds [ow, 2] = (first input column, tap count), xk [ow, kx]
+ * = round(tap * 2^22); ybounds / yk likewise for rows.  A pass whose size does not change is skipped (tables may be
+ * NULL), as in Pillow. */
+int anyref_op_pil_resample_u8(void* stream, const uint8_t* in, int H, int W, int C, uint8_t* tmp, uint8_t* out,
+                              int ow, int oh, const int32_t* xbounds, const int32_t* xk, int kx,
+                              const int32_t* ybounds, const int32_t* yk, int ky);
+/* SURVEY.md §8 f-1, the rest of the CLIP input path (utils/refer_seg.py:578-587): window [y0, y0+h) x [x0, x0+w) of
+ * img u8 [ih, iw, 3] dev -> x * (1/255) (in double, then f32) -> (x - mean3[c]) / std3[c] -> bilinear
+ * (align_corners = False) to out f32 CHW [3, S, S] dev.  mean3 / std3 are HOST pointers. */
+int anyref_op_clip_finish(void* stream, const uint8_t* img, int ih, int iw, int y0, int x0, int h, int w, int S,
+                          const float* mean3, const float* std3, float* out);
 /* bf16 window attention with the decomposed rel-pos bias computed inside the kernel from the tables
  * (image_encoder.py:321-392 get_rel_pos / add_decomposed_rel_pos): tab_h bf16 [2*kh-1, hd], tab_w bf16 [2*kw-1, hd],
  * rows at stride tab_ld elements; S = kh*kw tokens, [B,S,H,hd] operands.  Only the shapes the resident-key form
