@@ -288,6 +288,7 @@ void launch_fill_rows_bias(void* dst, int ld, const int* rows, int nrows, const 
 void launch_iou_counts(const float* logits, const uint8_t* target, int n, int64_t hw, int64_t* counts, hipStream_t s);
 void launch_avs_counts(const float* logits, const uint8_t* target, int n, int64_t hw, const float* cuts, int nth,
                        float cut_pred, int64_t* conf, int64_t* hist, hipStream_t s);
+void launch_pool_ref_tokens(const float* f, int n, int L, int H, int n_out, float* out, hipStream_t s);
 void launch_pil_resample_u8(const uint8_t* in, int H, int W, int C, uint8_t* tmp, uint8_t* out, int ow, int oh,
                             const int* xbounds, const int* xk, int kx, const int* ybounds, const int* yk, int ky,
                             hipStream_t s);

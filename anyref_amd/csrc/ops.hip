@@ -1108,6 +1108,35 @@ void launch_clip_finish(const uint8_t* img, int ih, int iw, int y0, int x0, int 
                      h, w, S, mean[0], mean[1], mean[2], std_[0], std_[1], std_[2], out);
 }
 
+// f-3: reference-image tokens (anyref.py:335-338, :697-700): [n, L, H] CLIP features -> mean over groups of 16
+// consecutive tokens -> [n, L/16, H] -> (if L/16 != n_out) mean over groups of n_out consecutive rows -> [n, n_out, H].
+// Two rounded means in the reference's order (not one mean over 64 tokens).
+__global__ __launch_bounds__(256) void pool_ref_tokens_kernel(const float* __restrict__ f, int L, int H, int n_out,
+                                                              float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int n16 = L / 16;
+  const bool second = n16 != n_out;
+  if (i >= (int64_t)n_out * H) return;
+  const int c = (int)(i % H), j = (int)(i / H);
+  const float* base = f + (int64_t)blockIdx.y * L * H + c;
+  const int per = second ? n_out : 1;                 // 16-token means per output row
+  float acc2 = 0.f;
+  for (int g = 0; g < per; ++g) {
+    const float* p = base + (int64_t)(j * per + g) * 16 * H;
+    float acc = 0.f;
+    for (int t = 0; t < 16; ++t) acc += p[(int64_t)t * H];
+    acc2 += acc / 16.f;
+  }
+  out[(int64_t)blockIdx.y * n_out * H + i] = second ? acc2 / (float)per : acc2;
+}
+void launch_pool_ref_tokens(const float* f, int n, int L, int H, int n_out, float* out, hipStream_t s) {
+  if (n <= 0) return;
+  if (L % 16 || (L / 16 != n_out && L / 16 != n_out * n_out))
+    throw std::runtime_error("pool_ref_tokens: token count must be 16 * n_out or 16 * n_out^2 (anyref.py:335-338)");
+  hipLaunchKernelGGL(pool_ref_tokens_kernel, dim3((unsigned)cdiv64((int64_t)n_out * H, 256), n), dim3(256), 0, s, f, L, H,
+                     n_out, out);
+}
+
 // rows[i] of dst <- bias (SAM window layers: q/k/v of a zero-padded token is exactly the bias)
 template <typename T>
 __global__ __launch_bounds__(256) void fill_rows_bias_kernel(T* __restrict__ dst, int ld, const int* __restrict__ rows,

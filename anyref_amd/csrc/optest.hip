@@ -148,6 +148,10 @@ int anyref_op_pil_resample_u8(void* stream, const uint8_t* in, int H, int W, int
   OP_GUARD(launch_pil_resample_u8(in, H, W, C, tmp, out, ow, oh, xbounds, xk, kx, ybounds, yk, ky, (hipStream_t)stream));
 }
 
+int anyref_op_pool_ref_tokens(void* stream, const float* feats, int n, int L, int H, int n_out, float* out) {
+  OP_GUARD(launch_pool_ref_tokens(feats, n, L, H, n_out, out, (hipStream_t)stream));
+}
+
 int anyref_op_clip_finish(void* stream, const uint8_t* img, int ih, int iw, int y0, int x0, int h, int w, int S,
                           const float* mean3, const float* std3, float* out) {
   OP_GUARD(launch_clip_finish(img, ih, iw, y0, x0, h, w, S, mean3, std3, out, (hipStream_t)stream));

@@ -426,25 +426,35 @@ class AnyRefForCausalLM:
         s = torch.tensor(slots, dtype=torch.int32).contiguous()
         return e, s, e.shape[0]
 
-    def _ref_features(self, ref_images):
-        """`ref_images` branch (anyref.py:681-702): CLIP features pooled 256 -> 16 -> IMG_REF_NUM."""
+    def _ref_features(self, ref_images, B: int):
+        """`ref_images` branch of generate (anyref.py:681-702) / forward (:319-339): every reference image goes
+        through `encode_images` (a second CLIP pass) and ends as IMG_REF_NUM rows that replace the prompt's
+        `<img_ref>` placeholders.  The reference pools a TENSOR batch 256 -> 16 -> 4 in the glue (:695-700) but hands
+        LIST items to the absent llava layer unpooled (:691-692); this backend's reading of that layer (INFERRED,
+        documented in DESIGN.md) pools them the way `model_forward_new` does (:335-338), so both forms take the
+        same kernel (`anyref_op_pool_ref_tokens`).  1-D items are RoI coordinates (:688-689): need the llava layer."""
         if ref_images is None:
             return None
         from .config import IMG_REF_NUM
+        if isinstance(ref_images, (list, tuple)):
+            items = list(ref_images)
+        else:
+            if ref_images.dim() != 4 or ref_images.shape[0] != B:          # anyref.py:695,701-702
+                raise NotImplementedError("a ref_images tensor must be [batch, 3, S, S]")
+            items = list(ref_images)
         feats = []
-        items = ref_images if isinstance(ref_images, (list, tuple)) else list(ref_images)
         for r in items:
             if r is None:
                 feats.append(None)
                 continue
             if r.dim() == 1:
                 raise NotImplementedError("RoI-coordinate reference (anyref.py:688-689) needs the absent llava layer")
-            f = self.encode_images(r[None].float())[0]                    # [256, H]
-            ll, c = f.shape
-            f = f.reshape(ll // 16, 16, c).mean(1)
-            if f.shape[0] != IMG_REF_NUM:
-                f = f.reshape(IMG_REF_NUM, IMG_REF_NUM, c).mean(1)
-            feats.append(f)
+            f = self.encode_images(r[None].float())                      # [1, 256, H]
+            out = torch.empty(1, IMG_REF_NUM, f.shape[2], device=self.device, dtype=torch.float32)
+            rc = self.lib.anyref_op_pool_ref_tokens(self._stream(), _ptr(f), 1, f.shape[1], f.shape[2], IMG_REF_NUM, _ptr(out))
+            if rc != 0:
+                raise RuntimeError("pool_ref_tokens: " + self.lib.anyref_op_last_error().decode())
+            feats.append(out[0])
         return feats
 
     # ---- stage calls (used by tests and by callers that want the pieces) -------------------
@@ -539,7 +549,7 @@ class AnyRefForCausalLM:
             raise ValueError(f"batch {B} > max_batch {self.max_batch} the handle was created for")
         clip = clip_images.to(self.device, torch.float32).contiguous()
         sam = sam_images.to(self.device, torch.float32).contiguous()
-        extra, slots, n_extra = self._extra(ids, lens, audios, self._ref_features(ref_images))
+        extra, slots, n_extra = self._extra(ids, lens, audios, self._ref_features(ref_images, B))
         height = [int(h) for h in height]
         width = [int(w) for w in width]
         rs = torch.tensor([[int(a), int(b)] for a, b in sam_resized_sizes], dtype=torch.int32).contiguous()
@@ -598,7 +608,7 @@ class AnyRefForCausalLM:
         lab_rows, _ = self._rows(labels, attention_masks)
         clip = clip_images.to(self.device, torch.float32).contiguous()
         sam = sam_images.to(self.device, torch.float32).contiguous()
-        extra, slots, n_extra = self._extra(ids, lens, audios, self._ref_features(ref_images))
+        extra, slots, n_extra = self._extra(ids, lens, audios, self._ref_features(ref_images, B))
         height = [int(h) for h in height]
         width = [int(w) for w in width]
         rs = torch.tensor([[int(a), int(b)] for a, b in sam_resized_sizes], dtype=torch.int32).contiguous()

@@ -65,6 +65,10 @@ int anyref_op_sam_preprocess(void* stream, const uint8_t* img, int h, int w, int
 int anyref_op_pil_resample_u8(void* stream, const uint8_t* in, int H, int W, int C, uint8_t* tmp, uint8_t* out,
                               int ow, int oh, const int32_t* xbounds, const int32_t* xk, int kx,
                               const int32_t* ybounds, const int32_t* yk, int ky);
+/* SURVEY.md §8 f-3, the token pooling of the `ref_images` branch (model/anyref.py:335-338, :697-700): feats f32
+ * [n, L, H] dev (`encode_images` output, L = 256) -> mean over groups of 16 tokens -> (L/16 != n_out) mean over
+ * groups of n_out rows -> out f32 [n, n_out, H] dev (n_out = IMG_REF_NUM = 4). */
+int anyref_op_pool_ref_tokens(void* stream, const float* feats, int n, int L, int H, int n_out, float* out);
 /* SURVEY.md §8 f-1, the rest of the CLIP input path (utils/refer_seg.py:578-587): window [y0, y0+h) x [x0, x0+w) of
  * img u8 [ih, iw, 3] dev -> x * (1/255) (in double, then f32) -> (x - mean3[c]) / std3[c] -> bilinear
  * (align_corners = False) to out f32 CHW [3, S, S] dev.  mean3 / std3 are HOST pointers. */
