@@ -76,7 +76,11 @@ def test_gemm(lib, ty, M, N, K, act):
 
 
 @pytest.mark.parametrize("M,N,K", [(4096, 3840, 128), (4096, 5120, 128), (4096, 1280, 192), (4096, 1280, 64),
-                                   (4096, 1280, 448), (320, 12288, 128), (320, 22016, 192), (4900, 1280, 128)])
+                                   (4096, 1280, 448), (320, 12288, 128), (320, 22016, 192), (4900, 1280, 128),
+                                   # 13B (config 5): prefill qkv / gate-up widths, split-K o / down at full K,
+                                   # and the M = 8 rows of the MFMA decode path
+                                   (320, 15360, 128), (320, 27648, 192), (320, 5120, 5120), (320, 5120, 13824),
+                                   (8, 15360, 5120), (8, 5120, 13824), (2560, 15360, 128)])
 def test_gemm_tile_paths_of_the_big_shapes(lib, M, N, K):
     """the tile heuristics of launch_gemm at the SAM-H / LLaMA-7B output shapes (short K): 256^2, 256x320,
     128x160 (ragged LDS-DMA round, 1 .. 7 K tiles through the 3-stage ring), 64x256 with 3 / 2 stages, 128^2"""
@@ -86,7 +90,7 @@ def test_gemm_tile_paths_of_the_big_shapes(lib, M, N, K):
     ref = rnd(A, 1) @ rnd(W, 1).t() + bias
     out = torch.empty(M, N, device="cuda")
     check(lib, lib.anyref_op_gemm(1, None, P(dev(A, 1)), P(dev(W, 1)), P(bias.cuda()), P(out), None, None, M, N, K, 0, 1))
-    close(out, ref, 1e-4)            # bf16 products are exact in f32; only the summation order differs
+    close(out, ref, 1e-4 if K < 2048 else 4e-4)   # bf16 products are exact in f32; only the summation order differs
 
 
 @pytest.mark.parametrize("ty", [0, 1])
@@ -109,7 +113,11 @@ def test_gemm_row_map_and_typed_out(lib, ty):
 
 @pytest.mark.parametrize("ty", [0, 1])
 @pytest.mark.parametrize("B,N,K,dual,norm", [(1, 512, 256, 0, 1), (2, 1000, 688, 1, 1), (4, 300, 1024, 0, 0),
-                                             (3, 64, 4096, 1, 0), (1, 33, 11008, 0, 1)])
+                                             (3, 64, 4096, 1, 0), (1, 33, 11008, 0, 1),
+                                             # the 13B widths config 5 selects (K = 5120 -> 24 x-values per thread,
+                                             # K = 13824 -> 32, neither a multiple of 512 * 8) and the ragged lm_head
+                                             (1, 640, 5120, 0, 1), (2, 130, 5120, 1, 1), (1, 64, 13824, 0, 0),
+                                             (4, 40, 13824, 0, 1), (2, 96, 13824, 1, 0), (1, 32007, 4096, 0, 1)])
 def test_gemv(lib, ty, B, N, K, dual, norm):
     g = torch.Generator().manual_seed(B + N + K)
     x = torch.randn(B, K, generator=g)
