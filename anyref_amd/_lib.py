@@ -11,7 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libanyref_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 F32, BF16, F16 = 0, 1, 2
 MODE_PARITY, MODE_PERF, MODE_PERF_FP8W = 0, 1, 2
 
@@ -34,6 +34,8 @@ class AnyrefConfig(C.Structure):
         ("seg_lo", C.c_int32), ("seg_hi", C.c_int32),
         ("rephrase_weight", C.c_float),
         ("max_batch", C.c_int32), ("max_seg", C.c_int32),
+        ("aud_dim", C.c_int32), ("aud_blocks", C.c_int32), ("aud_heads", C.c_int32), ("aud_mel", C.c_int32),
+        ("aud_len", C.c_int32), ("aud_kernel", C.c_int32), ("aud_stride", C.c_int32), ("aud_clips", C.c_int32),
     ]
 
 
@@ -58,6 +60,7 @@ SYMBOLS = {
     "anyref_mask_decode": (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
     "anyref_llm_forward": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
     "anyref_project_audio": (_I, [_P, _P, _P, _I, _P]),
+    "anyref_audio_encode": (_I, [_P, _P, _P, _I, _P]),
     "anyref_seg_tail": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _L, _P, _P]),
     "anyref_set_seg_range": (_I, [_P, _I, _I]),
     "anyref_set_overlap": (_I, [_P, _I]),

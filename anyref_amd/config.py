@@ -87,6 +87,23 @@ class SamConfig:
 
 
 @dataclass
+class AudioTrunkConfig:
+    """ImageBind audio trunk (model/ImageBind/models/imagebind_model.py:36-110,175-192 defaults of `imagebind_huge`)."""
+    dim: int = 768
+    blocks: int = 12
+    heads: int = 12
+    mel_bins: int = 128
+    target_len: int = 204
+    kernel: int = 16
+    stride: int = 10
+    clips: int = 3                   # clips per sample (utils/avsbench.py:256-259)
+
+    @property
+    def n_patches(self) -> int:
+        return ((self.mel_bins - self.kernel) // self.stride + 1) * ((self.target_len - self.kernel) // self.stride + 1)
+
+
+@dataclass
 class AnyRefConfig:
     clip: ClipConfig = field(default_factory=ClipConfig)
     llm: LlmConfig = field(default_factory=LlmConfig)
@@ -98,6 +115,9 @@ class AnyRefConfig:
     bos_token_id: int = 1
     pad_token_id: int = 0
     audio_dim: int = 1024            # ImageBind audio embedding width (imagebind_model.py:425-428)
+    # None: the ImageBind trunk stays a PyTorch-ROCm module outside the handle (north_star's default);
+    # an AudioTrunkConfig: the trunk runs in HIP inside the handle (SURVEY.md §8 f-4), given `model.audio_encoder.*`
+    audio_trunk: "AudioTrunkConfig" = None
 
     def seg_range(self) -> Tuple[int, int]:
         """[lo, hi] inclusive id range that counts as a [SEG] token (anyref.py:197-200,723-726)."""

@@ -109,6 +109,10 @@ int anyref_llm_forward(anyref_handle* h, void* stream, const float* embeds, cons
   GUARD(h, h->m->llm_forward((hipStream_t)stream, embeds, lens, B, S, hidden, logits, attn_q, attn_row));
 }
 
+int anyref_audio_encode(anyref_handle* h, void* stream, const float* mel, int n, float* emb) {
+  GUARD(h, h->m->audio_encode((hipStream_t)stream, mel, n, emb));
+}
+
 int anyref_project_audio(anyref_handle* h, void* stream, const float* audio_emb, int n, float* out) {
   GUARD(h, h->m->project_audio((hipStream_t)stream, audio_emb, n, out));
 }

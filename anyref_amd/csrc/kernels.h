@@ -232,7 +232,11 @@ template <typename T>
 void launch_add_rows_to(const float* a, const float* b, int bmod, void* out, int M, int D, hipStream_t s);
 // CLIP embeddings: x[b,0]=cls+pos[0]; x[b,1+i]=patch[b,i]+pos[1+i]   (f32)
 void launch_clip_assemble(const float* patch, const float* cls, const float* pos, float* x, int B, int n,
-                          int D, hipStream_t s);
+                          int D, hipStream_t s, int rows = 0);  // rows > n + 1: zeroed spare rows per item
+// ImageBind audio stem im2col (1 input channel, k x k kernel, stride st < k) and head tail (L2-normalise x scale)
+template <typename T>
+void launch_im2col_conv1(const float* img, int n, int Hh, int Ww, int k, int st, void* out, hipStream_t s);
+void launch_l2norm_scale(const float* x, int rows, int D, float scale, float* y, hipStream_t s);
 // token embedding gather + multimodal splice (LLaVA prepare_inputs; see oracle.splice_embeddings)
 // ids i64 dev [B,Lmax], lens i32 dev [B]; image placeholder (-200) expands to n_img rows of img_feat[b].
 // extra rows replace 1:1.  x f32 [B,Smax,D]; out_len i32 dev [B] (= len + n_img - 1 when an image is present).

@@ -50,6 +50,7 @@ class ModelBase {
   virtual void llm_forward(hipStream_t s, const float* embeds, const int32_t* lens, int B, int S, float* hidden,
                            float* logits, const int32_t* attn_q, float* attn_row) = 0;
   virtual void project_audio(hipStream_t s, const float* audio_emb, int n, float* out) = 0;
+  virtual void audio_encode(hipStream_t s, const float* mel, int n, float* emb) = 0;
   virtual void seg_tail(hipStream_t s, const float* sam_images, const int64_t* ids, const int32_t* ids_lens,
                         const int32_t* ref_pos, int B, int Lmax, int teacher, const float* hidden, int hidden_rows,
                         const float* attn_mean, const int32_t* resized_hw, const int32_t* orig_hw,

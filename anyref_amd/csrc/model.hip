@@ -160,6 +160,7 @@ class Model : public ModelBase {
   void llm_forward(hipStream_t s, const float* embeds, const int32_t* lens, int B, int S, float* hidden,
                    float* logits, const int32_t* attn_q, float* attn_row) override;
   void project_audio(hipStream_t s, const float* audio_emb, int n, float* out) override;
+  void audio_encode(hipStream_t s, const float* mel, int n, float* emb) override;
   void seg_tail(hipStream_t s, const float* sam_images, const int64_t* ids, const int32_t* ids_lens,
                 const int32_t* ref_pos, int B, int Lmax, int teacher, const float* hidden, int hidden_rows,
                 const float* attn_mean, const int32_t* resized_hw, const int32_t* orig_hw, int32_t* out_nseg,
@@ -329,6 +330,21 @@ class Model : public ModelBase {
   int *lens_dev_ = nullptr, *slen_dev_ = nullptr, *pos_dev_ = nullptr, *kvlen_dev_ = nullptr, *rowmap_dev_ = nullptr,
       *idx_a_ = nullptr, *idx_b_ = nullptr;
   int64_t* next_host_ = nullptr;  // pinned
+
+  // ---- ImageBind audio trunk (f-4; present iff cfg.aud_blocks > 0) ----
+  struct AudBlock {
+    Affine ln1, ln2;
+    Lin<T> qkv, out, fc1, fc2;
+    float *bias_k = nullptr, *bias_v = nullptr;
+  };
+  std::vector<AudBlock> aud_blocks_;
+  Lin<T> aud_stem_, aud_head_;
+  Affine aud_stem_ln_, aud_head_ln_;
+  float *aud_cls_ = nullptr, *aud_pos_ = nullptr, aud_scale_ = 20.f;
+  int aud_np_ = 0, aud_rows_ = 0;   // patches per clip; rows per clip in the work buffers (tokens + 1 spare)
+  int* aud_kvrow_ = nullptr;        // the spare row of every clip (holds bias_k / bias_v as the extra key / value)
+  T *a_col_ = nullptr, *a_h_ = nullptr, *a_qkv_ = nullptr, *a_att_ = nullptr, *a_mlp_ = nullptr, *a_clsrow_ = nullptr;
+  float *a_patch_ = nullptr, *a_x_ = nullptr, *a_emb_ = nullptr;
 
   // ---- glue ----
   LinF fc1_, fc2_;
@@ -823,6 +839,55 @@ void Model<T>::finalize() {
     m_masks_ = talloc<float>((size_t)n * nt * 16 * NK);
     m_iou_ = talloc<float>((size_t)n * nt);
   }
+  // ================= ImageBind audio trunk =================
+  if (c.aud_blocks > 0) {
+    const std::string ap = "model.audio_encoder.";
+    const int D = c.aud_dim, k = c.aud_kernel, st = c.aud_stride;
+    if (D % c.aud_heads || k * k % 64 || c.aud_clips < 1) throw std::runtime_error("audio trunk: unsupported shape");
+    const int gh = (c.aud_mel - k) / st + 1, gw = (c.aud_len - k) / st + 1;
+    aud_np_ = gh * gw;
+    aud_rows_ = aud_np_ + 2;  // [CLS] + patches + the add_bias_kv row
+    const std::string pp = ap + "modality_preprocessors.audio.";
+    aud_stem_ = pack_linear(pp + "rgbt_stem.proj.weight", "", D, k * k, 64);
+    aud_stem_ln_ = affine(pp + "rgbt_stem.norm_layer");
+    aud_cls_ = own_f32(pp + "cls_token");
+    aud_pos_ = own_f32(pp + "pos_embedding_helper.pos_embed");
+    if (raw(pp + "pos_embedding_helper.pos_embed").numel() != (int64_t)(aud_np_ + 1) * D)
+      throw std::runtime_error("audio pos_embed does not match the mel / kernel / stride geometry");
+    aud_blocks_.resize(c.aud_blocks);
+    for (int i = 0; i < c.aud_blocks; ++i) {
+      const std::string bp = ap + "modality_trunks.audio.blocks." + std::to_string(i) + ".";
+      AudBlock& Bk = aud_blocks_[i];
+      Bk.ln1 = affine(bp + "norm_1");
+      Bk.ln2 = affine(bp + "norm_2");
+      Bk.qkv = pack_linear(bp + "attn.in_proj_weight", bp + "attn.in_proj_bias", 3 * D, D);
+      Bk.out = pack_linear(bp + "attn.out_proj.weight", bp + "attn.out_proj.bias", D, D);
+      Bk.bias_k = own_f32(bp + "attn.bias_k");
+      Bk.bias_v = own_f32(bp + "attn.bias_v");
+      Bk.fc1 = pack_linear(bp + "mlp.fc1.weight", bp + "mlp.fc1.bias", 4 * D, D);
+      Bk.fc2 = pack_linear(bp + "mlp.fc2.weight", bp + "mlp.fc2.bias", D, 4 * D);
+    }
+    aud_head_ln_ = affine(ap + "modality_heads.audio.0");
+    aud_head_ = pack_linear(ap + "modality_heads.audio.2.weight", "", c.audio_dim, D);
+    const std::vector<float> ls = to_host(ap + "modality_postprocessors.audio.1.log_logit_scale");
+    aud_scale_ = std::min(expf(ls.at(0)), 100.f);  // LearnableLogitScaling: clip(exp(log_scale), max = 100)
+    const int NC = c.aud_clips * MB;
+    const size_t Rr = (size_t)NC * aud_rows_;
+    a_col_ = talloc<T>((size_t)NC * aud_np_ * k * k);
+    a_patch_ = talloc<float>((size_t)NC * aud_np_ * D);
+    a_x_ = talloc<float>(Rr * D);
+    a_h_ = talloc<T>(Rr * D);
+    a_qkv_ = talloc<T>(Rr * 3 * D);
+    a_att_ = talloc<T>(Rr * D);
+    HIP_TRY(hipMemset(a_att_, 0, Rr * D * sizeof(T)));  // the spare rows are never written by the attention
+    a_mlp_ = talloc<T>(Rr * 4 * D);
+    a_clsrow_ = talloc<T>((size_t)NC * D);
+    a_emb_ = talloc<float>((size_t)NC * c.audio_dim);
+    std::vector<int> rows(NC);
+    for (int i = 0; i < NC; ++i) rows[i] = i * aud_rows_ + aud_np_ + 1;
+    aud_kvrow_ = talloc<int>(NC);
+    HIP_TRY(hipMemcpy(aud_kvrow_, rows.data(), NC * sizeof(int), hipMemcpyHostToDevice));
+  }
   {
     int least = 0, greatest = 0;  // the side stream yields to the caller's stream
     HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
@@ -938,6 +1003,45 @@ void Model<T>::encode_images(hipStream_t s, const float* clip_images, int B, flo
       HIP_TRY(hipMemcpyAsync(clip_feat + (size_t)b * clip_n_ * cfg.clip_dim,
                              c_x_ + ((size_t)b * (clip_n_ + 1) + 1) * cfg.clip_dim,
                              (size_t)clip_n_ * cfg.clip_dim * 4, hipMemcpyDeviceToDevice, s));
+}
+
+// ImageBindModel.get_audio_feature (imagebind_model.py:477-511), the embedding half: see anyref_audio_encode
+template <typename T>
+void Model<T>::audio_encode(hipStream_t s, const float* mel, int n, float* emb) {
+  HIP_TRY(hipSetDevice(device_));
+  const anyref_config& c = cfg;
+  if (aud_blocks_.empty()) throw std::runtime_error("this handle has no ImageBind audio trunk (aud_blocks = 0)");
+  if (n < 1 || n > c.aud_clips * c.max_batch) throw std::runtime_error("audio_encode: too many clips for max_batch");
+  const int D = c.aud_dim, nh = c.aud_heads, hd = D / nh, np = aud_np_, RS = aud_rows_, R = n * RS, St = np + 1;
+  // stem: conv (no bias) as im2col + GEMM, LayerNorm, [CLS] + positions (multimodal_preprocessors.py:121-157,255-271)
+  launch_im2col_conv1<T>(mel, n, c.aud_mel, c.aud_len, c.aud_kernel, c.aud_stride, a_col_, s);
+  gemm(s, a_col_, aud_stem_.k, aud_stem_, a_patch_, D, n * np, ACT_NONE, true);
+  norm(s, a_patch_, D, aud_stem_ln_, a_patch_, D, n * np, D, 1e-5f, true);
+  launch_clip_assemble(a_patch_, aud_cls_, aud_pos_, a_x_, n, np, D, s, RS);
+  for (auto& Bk : aud_blocks_) {  // pre-LN blocks (transformer.py:94-170), nn.MultiheadAttention(add_bias_kv=True)
+    norm(s, a_x_, D, Bk.ln1, a_h_, D, R, D, 1e-6f, false);
+    gemm(s, a_h_, D, Bk.qkv, a_qkv_, 3 * D, R, ACT_NONE, false);
+    // the appended key / value of every clip is the learned bias_k / bias_v row (not projected)
+    launch_fill_rows_bias<T>(a_qkv_ + D, 3 * D, aud_kvrow_, n, Bk.bias_k, D, s);
+    launch_fill_rows_bias<T>(a_qkv_ + 2 * D, 3 * D, aud_kvrow_, n, Bk.bias_v, D, s);
+    AttnArgs a;
+    a.Q = a_qkv_; a.K = a_qkv_ + D; a.V = a_qkv_ + 2 * D; a.O = a_att_;
+    a.q_bs = a.k_bs = a.v_bs = (int64_t)RS * 3 * D;
+    a.q_rs = a.k_rs = a.v_rs = 3 * D;
+    a.q_hs = a.k_hs = a.v_hs = hd;
+    a.o_bs = (int64_t)RS * D; a.o_rs = D; a.o_hs = hd;
+    a.B = n; a.H = nh; a.Sq = St; a.Sk = St + 1; a.hd = hd;
+    a.scale = 1.f / sqrtf((float)hd);
+    launch_attention<T>(a, s);
+    gemm(s, a_att_, D, Bk.out, a_x_, D, R, ACT_NONE, true, a_x_, D);
+    norm(s, a_x_, D, Bk.ln2, a_h_, D, R, D, 1e-6f, false);
+    gemm(s, a_h_, D, Bk.fc1, a_mlp_, 4 * D, R, ACT_GELU, false);
+    gemm(s, a_mlp_, 4 * D, Bk.fc2, a_x_, D, R, ACT_NONE, true, a_x_, D);
+  }
+  // head: LayerNorm -> [CLS] -> Linear (no bias) -> L2-normalise x logit scale (imagebind_model.py:391-395,425-428)
+  norm(s, a_x_, RS * D, aud_head_ln_, a_clsrow_, D, n, D, 1e-6f, false);
+  gemm(s, a_clsrow_, D, aud_head_, a_emb_, c.audio_dim, n, ACT_NONE, true);
+  launch_l2norm_scale(a_emb_, n, c.audio_dim, aud_scale_, emb, s);
 }
 
 template <typename T>

@@ -381,23 +381,73 @@ void launch_add_vec(const float* a, const float* v, float* out, int M, int D, hi
   hipLaunchKernelGGL(add_vec_kernel, dim3(grid), dim3(256), 0, s, a, v, out, M, D);
 }
 
+// x[b, t, :] = (t == 0 ? cls : patch[b, t-1, :]) + pos[t, :] for t <= n; rows n+1 .. rows-1 of an item are zeroed
+// (the audio trunk keeps one spare row per clip for the `add_bias_kv` key / value)
 __global__ void clip_assemble_kernel(const float* __restrict__ patch, const float* __restrict__ cls,
-                                     const float* __restrict__ pos, float* __restrict__ x, int B, int n, int D) {
-  const int64_t total = (int64_t)B * (n + 1) * D;
+                                     const float* __restrict__ pos, float* __restrict__ x, int B, int n, int D,
+                                     int rows) {
+  const int64_t total = (int64_t)B * rows * D;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
        i += (int64_t)gridDim.x * blockDim.x) {
     const int d = (int)(i % D);
-    const int t = (int)((i / D) % (n + 1));
-    const int b = (int)(i / ((int64_t)D * (n + 1)));
+    const int t = (int)((i / D) % rows);
+    const int b = (int)(i / ((int64_t)D * rows));
+    if (t > n) {
+      x[i] = 0.f;
+      continue;
+    }
     const float v = t == 0 ? cls[d] : patch[((int64_t)b * n + (t - 1)) * D + d];
     x[i] = v + pos[(int64_t)t * D + d];
   }
 }
 void launch_clip_assemble(const float* patch, const float* cls, const float* pos, float* x, int B, int n, int D,
-                          hipStream_t s) {
-  const int64_t total = (int64_t)B * (n + 1) * D;
+                          hipStream_t s, int rows) {
+  if (rows <= 0) rows = n + 1;
+  const int64_t total = (int64_t)B * rows * D;
   const int grid = (int)(cdiv64(total, 256) < 8192 ? cdiv64(total, 256) : 8192);
-  hipLaunchKernelGGL(clip_assemble_kernel, dim3(grid), dim3(256), 0, s, patch, cls, pos, x, B, n, D);
+  hipLaunchKernelGGL(clip_assemble_kernel, dim3(grid), dim3(256), 0, s, patch, cls, pos, x, B, n, D, rows);
+}
+
+// f-4: ImageBind audio stem (imagebind_model.py:175-192: Conv2d(1, D, k, stride < k, bias=False) on the mel
+// spectrogram) as im2col + GEMM: img f32 [n, 1, Hh, Ww] -> out T [n * gh * gw, k * k], patches overlap
+template <typename T>
+__global__ void im2col_conv1_kernel(const float* __restrict__ img, int n, int Hh, int Ww, int k, int st, int gh, int gw,
+                                    T* __restrict__ out) {
+  const int KK = k * k;
+  const int64_t total = (int64_t)n * gh * gw * KK;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int e = (int)(i % KK);
+    const int64_t row = i / KK;
+    const int px = (int)(row % gw), py = (int)((row / gw) % gh), b = (int)(row / ((int64_t)gh * gw));
+    out[i] = from_f32<T>(img[((int64_t)b * Hh + py * st + e / k) * Ww + px * st + e % k]);
+  }
+}
+template <typename T>
+void launch_im2col_conv1(const float* img, int n, int Hh, int Ww, int k, int st, void* out, hipStream_t s) {
+  const int gh = (Hh - k) / st + 1, gw = (Ww - k) / st + 1;
+  const int64_t total = (int64_t)n * gh * gw * k * k;
+  const int grid = (int)(cdiv64(total, 256) < 4096 ? cdiv64(total, 256) : 4096);
+  hipLaunchKernelGGL((im2col_conv1_kernel<T>), dim3(grid), dim3(256), 0, s, img, n, Hh, Ww, k, st, gh, gw,
+                     reinterpret_cast<T*>(out));
+}
+template void launch_im2col_conv1<float>(const float*, int, int, int, int, int, void*, hipStream_t);
+template void launch_im2col_conv1<bf16>(const float*, int, int, int, int, int, void*, hipStream_t);
+
+// f-4: ImageBind audio head tail (imagebind_model.py:425-428): y = x / max(||x||_2, 1e-12) * scale, one block per row
+__global__ __launch_bounds__(256) void l2norm_scale_kernel(const float* __restrict__ x, int D, float scale,
+                                                           float* __restrict__ y) {
+  const float* r = x + (int64_t)blockIdx.x * D;
+  float ss = 0.f;
+  for (int d = threadIdx.x; d < D; d += 256) ss += r[d] * r[d];
+  ss = wave_sum(ss);
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+  __syncthreads();
+  const float nrm = fmaxf(sqrtf(red[0] + red[1] + red[2] + red[3]), 1e-12f);
+  for (int d = threadIdx.x; d < D; d += 256) y[(int64_t)blockIdx.x * D + d] = r[d] / nrm * scale;
+}
+void launch_l2norm_scale(const float* x, int rows, int D, float scale, float* y, hipStream_t s) {
+  if (rows > 0) hipLaunchKernelGGL(l2norm_scale_kernel, dim3(rows), dim3(256), 0, s, x, D, scale, y);
 }
 
 // ---------------------------------------------------------------------------------------------

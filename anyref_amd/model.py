@@ -57,12 +57,16 @@ def _c_config(cfg: AnyRefConfig, mode: int, max_batch: int, max_seg: int) -> _li
     c.seg_lo, c.seg_hi = cfg.seg_range()
     c.rephrase_weight = float(cfg.rephrase_weight)
     c.max_batch, c.max_seg = max_batch, max_seg
+    at = cfg.audio_trunk
+    if at is not None:
+        c.aud_dim, c.aud_blocks, c.aud_heads, c.aud_mel = at.dim, at.blocks, at.heads, at.mel_bins
+        c.aud_len, c.aud_kernel, c.aud_stride, c.aud_clips = at.target_len, at.kernel, at.stride, at.clips
     return c
 
 
 _NEEDS_HANDLE = frozenset({
     "generate", "model_forward_new", "forward", "__call__", "encode_images", "sam_encode", "mask_decode", "llm_forward",
-    "seg_tail", "postprocess", "device_bytes", "set_overlap", "set_graphs", "profile_enable", "profile_read"})
+    "seg_tail", "postprocess", "audio_encode", "device_bytes", "set_overlap", "set_graphs", "profile_enable", "profile_read"})
 
 
 class AnyRefForCausalLM:
@@ -174,6 +178,12 @@ class AnyRefForCausalLM:
 
     @classmethod
     def from_state_dict(cls, cfg: AnyRefConfig, sd, **kw) -> "AnyRefForCausalLM":
+        if cfg.audio_trunk is None and any(k.startswith("model.audio_encoder.modality_trunks.audio.") for k in sd):
+            from .config import AudioTrunkConfig          # the checkpoint carries the ImageBind trunk: run it in HIP
+            cfg.audio_trunk = AudioTrunkConfig(
+                dim=sd["model.audio_encoder.modality_heads.audio.0.weight"].shape[0],
+                blocks=1 + max(int(k.split("blocks.")[1].split(".")[0]) for k in sd
+                               if k.startswith("model.audio_encoder.modality_trunks.audio.blocks.")))
         m = cls(cfg, **kw)
         m.load_state_dict(sd)
         return m
@@ -396,10 +406,14 @@ class AnyRefForCausalLM:
                 if a is None:
                     continue
                 if a.dim() >= 4:     # raw mel clips [1,3,1,128,204] -> ImageBind embedding [3,1024]
-                    if self.audio_encoder is None:
-                        raise RuntimeError("raw audio given but no audio_encoder attached (anyref_amd.audio)")
-                    _, emb = self.audio_encoder.get_audio_feature(a.to(self.device).float())
-                    a = emb[0]
+                    if self.cfg.audio_trunk is not None:          # trunk inside the handle (HIP, f-4)
+                        a = self.audio_encode(a)
+                    elif self.audio_encoder is not None:           # PyTorch-ROCm module (north_star's default)
+                        _, emb = self.audio_encoder.get_audio_feature(a.to(self.device).float())
+                        a = emb[0]
+                    else:
+                        raise RuntimeError("raw audio given but neither a HIP trunk (cfg.audio_trunk + model.audio_encoder.* "
+                                           "weights) nor an audio_encoder module (anyref_amd.audio) is attached")
                 a = a.to(self.device, torch.float32).reshape(-1, self.cfg.audio_dim).contiguous()
                 out = torch.empty(a.shape[0], self.cfg.llm.dim, device=self.device, dtype=torch.float32)
                 self._check(self.lib.anyref_project_audio(self.h, self._stream(), _ptr(a), a.shape[0], _ptr(out)),
@@ -466,6 +480,17 @@ class AnyRefForCausalLM:
         self._check(self.lib.anyref_encode_images(self.h, self._stream(), _ptr(x), B, _ptr(out), _ptr(cf)),
                     "encode_images")
         return (out, cf) if return_clip else out
+
+    def audio_encode(self, mel: torch.Tensor) -> torch.Tensor:
+        """`get_audio_feature(...)[1]` (imagebind_model.py:477-511) in HIP: mel [..., 1, mel_bins, target_len] (any
+        leading clip / batch dims) -> embedding [n_clips, audio_dim], L2-normalised x logit scale."""
+        at = self.cfg.audio_trunk
+        if at is None:
+            raise RuntimeError("the handle was created without an audio trunk (cfg.audio_trunk is None)")
+        x = mel.to(self.device, torch.float32).reshape(-1, 1, at.mel_bins, at.target_len).contiguous()
+        out = torch.empty(x.shape[0], self.cfg.audio_dim, device=self.device, dtype=torch.float32)
+        self._check(self.lib.anyref_audio_encode(self.h, self._stream(), _ptr(x), x.shape[0], _ptr(out)), "audio_encode")
+        return out
 
     def sam_encode(self, sam_images: torch.Tensor) -> torch.Tensor:
         """-> [B, 256, g, g] (the reference's NCHW layout)."""

@@ -64,6 +64,34 @@ def weight_shapes(cfg: AnyRefConfig, audio: bool = True) -> Iterator[Tuple[str, 
     if audio:
         yield "model.audio_projector.weight", (l.dim, cfg.audio_dim), "w"
         yield "model.audio_projector.bias", (l.dim,), "b"
+    at = getattr(cfg, "audio_trunk", None)
+    if audio and at is not None:        # ImageBind audio trunk under the reference's `model.audio_encoder.` names
+        ap = "model.audio_encoder."
+        pp = ap + "modality_preprocessors.audio."
+        yield pp + "cls_token", (1, 1, at.dim), "w"
+        yield pp + "rgbt_stem.proj.weight", (at.dim, 1, at.kernel, at.kernel), "w"
+        yield pp + "rgbt_stem.norm_layer.weight", (at.dim,), "g"
+        yield pp + "rgbt_stem.norm_layer.bias", (at.dim,), "b"
+        yield pp + "pos_embedding_helper.pos_embed", (1, at.n_patches + 1, at.dim), "w"
+        for i in range(at.blocks):
+            bp = f"{ap}modality_trunks.audio.blocks.{i}."
+            yield bp + "attn.in_proj_weight", (3 * at.dim, at.dim), "w"
+            yield bp + "attn.in_proj_bias", (3 * at.dim,), "b"
+            yield bp + "attn.bias_k", (1, 1, at.dim), "b"
+            yield bp + "attn.bias_v", (1, 1, at.dim), "b"
+            yield bp + "attn.out_proj.weight", (at.dim, at.dim), "w"
+            yield bp + "attn.out_proj.bias", (at.dim,), "b"
+            for nm in ("norm_1", "norm_2"):
+                yield bp + nm + ".weight", (at.dim,), "g"
+                yield bp + nm + ".bias", (at.dim,), "b"
+            yield bp + "mlp.fc1.weight", (4 * at.dim, at.dim), "w"
+            yield bp + "mlp.fc1.bias", (4 * at.dim,), "b"
+            yield bp + "mlp.fc2.weight", (at.dim, 4 * at.dim), "w"
+            yield bp + "mlp.fc2.bias", (at.dim,), "b"
+        yield ap + "modality_heads.audio.0.weight", (at.dim,), "g"
+        yield ap + "modality_heads.audio.0.bias", (at.dim,), "b"
+        yield ap + "modality_heads.audio.2.weight", (cfg.audio_dim, at.dim), "w"
+        yield ap + "modality_postprocessors.audio.1.log_logit_scale", (), "ls"
 
     p = SAM_PREFIX + "image_encoder."
     g = s.grid
@@ -183,7 +211,9 @@ def synth_state_dict(cfg: AnyRefConfig, seed: int = 0, scale: float = 0.02, devi
             t = t * scale if jitter else torch.zeros_like(t)
         elif kind == "g":
             t = 1.0 + (t * 0.1 if jitter else 0.0 * t)
-        if round_bf16 and kind != "n1":
+        elif kind == "ls":
+            t = torch.full(shape, 2.995732273553991, device=device)      # log(20), imagebind_model.py:425-428
+        if round_bf16 and kind not in ("n1", "ls"):
             t = t.to(torch.bfloat16).to(torch.float32)
         out[name] = t.to(dtype)
     return out

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define ANYREF_ABI_VERSION 1
+#define ANYREF_ABI_VERSION 2
 
 /* dtype codes for anyref_set_weight */
 #define ANYREF_F32 0
@@ -59,6 +59,9 @@ typedef struct anyref_config {
   float rephrase_weight;
   int32_t max_batch; /* images per call on this GPU */
   int32_t max_seg;   /* [SEG] tokens per image the workspaces are sized for */
+  /* ImageBind audio trunk in HIP (imagebind_model.py:175-192,331-338,391-395,425-428).
+   * aud_blocks = 0: no trunk in the handle (the PyTorch-ROCm module feeds anyref_project_audio instead). */
+  int32_t aud_dim, aud_blocks, aud_heads, aud_mel, aud_len, aud_kernel, aud_stride, aud_clips;
 } anyref_config;
 
 typedef struct anyref_handle anyref_handle;
@@ -146,6 +149,14 @@ int anyref_mask_decode(anyref_handle* h, void* stream, const float* image_emb, c
  * query `attn_q[b]` (i32[B] host) over all keys (anyref.py:748-749). */
 int anyref_llm_forward(anyref_handle* h, void* stream, const float* embeds, const int32_t* lens, int B,
                        int S, float* hidden, float* logits, const int32_t* attn_q, float* attn_row);
+
+/* ImageBindModel.get_audio_feature, second return value (model/ImageBind/models/imagebind_model.py:477-511; call
+ * sites anyref.py:313-315, :670-672), for handles created with aud_blocks > 0 and given the
+ * `model.audio_encoder.*` weights: mel f32 dev [n, 1, aud_mel, aud_len] (n = clips, <= aud_clips * max_batch)
+ * -> conv stem (kernel aud_kernel, stride aud_stride, no bias) + LayerNorm -> [CLS] + pos_embed -> aud_blocks
+ * pre-LN blocks (MHA with add_bias_kv, GELU MLP x4) -> LayerNorm -> CLS -> Linear(aud_dim, audio_dim, no bias)
+ * -> L2-normalise x min(exp(log_logit_scale), 100) -> emb f32 dev [n, audio_dim]. */
+int anyref_audio_encode(anyref_handle* h, void* stream, const float* mel, int n, float* emb);
 
 /* audio_projector = Linear(audio_dim, llm_dim) on ImageBind audio embeddings (anyref.py:161,673).
  * audio_emb f32 [n, audio_dim] dev (the ImageBind trunk itself stays a PyTorch-ROCm step) ->

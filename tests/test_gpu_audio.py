@@ -1,0 +1,85 @@
+"""the ImageBind audio trunk inside the HIP handle (`anyref_audio_encode`) at its real size
+(768 wide, 12 blocks of 12 heads with add_bias_kv, 3 clips of 128 x 204 mel, conv stem k16 s10, 1024-d head) against
+the output of the REFERENCE's own `ImageBindModel.get_audio_feature` (tests/golden/imagebind_audio.npz, made by
+tests/golden/make_golden_audio.py) and against the PyTorch restatement; then the audio-referred path end to end
+(BASELINE configs[3] at plumbing size) with raw mel clips going through the HIP trunk."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import make_golden_audio as ga  # noqa: E402
+from anyref_amd.config import config_tiny, AudioTrunkConfig, IMAGE_TOKEN_INDEX, AUDIO_REF_INDEX  # noqa: E402
+from anyref_amd.synth import synth_state_dict  # noqa: E402
+from oracle import anyref_oracle as O  # noqa: E402
+
+# |emb| = 20 per row.  parity (f32): measured 3.8e-6 vs the reference; perf (bf16 trunk): measured 1.6e-2, bound = 2 x
+TOL = {"parity": 1e-3, "perf": 0.035}
+
+
+def _with_trunk(sd, trunk):
+    sd = dict(sd)
+    for k, v in trunk.state_dict().items():
+        sd["model.audio_encoder." + k] = v.detach().clone()
+    return sd
+
+
+@pytest.mark.parametrize("mode", ["parity", "perf"])
+def test_audio_trunk_real_size_vs_reference_fixture(mode):
+    from anyref_amd.model import AnyRefForCausalLM
+    fx = np.load(os.path.join(HERE, "golden", "imagebind_audio.npz"))
+    trunk = ga.seeded_audio_module()                       # the weights the reference ran with
+    mel = ga.audio_inputs()
+    cfg = config_tiny()
+    sd = _with_trunk(synth_state_dict(cfg, seed=3, scale=0.05), trunk)
+    m = AnyRefForCausalLM.from_state_dict(cfg, {k: v.cuda() for k, v in sd.items()}, mode=mode, max_batch=1)
+    assert m.cfg.audio_trunk is not None and m.cfg.audio_trunk.dim == 768 and m.cfg.audio_trunk.blocks == 12
+    emb = m.audio_encode(mel).cpu()
+    assert emb.shape == (3, 1024)
+    assert torch.allclose(emb.norm(dim=-1), torch.full((3,), 20.0), atol=1e-3)
+    e_ref = float(np.abs(emb.numpy() - fx["emb"][0]).max())
+    _, want = trunk.get_audio_feature(mel)
+    e_torch = float((emb - want[0]).abs().max())
+    print(f"[{mode}] HIP audio trunk: max-abs-err vs the reference's output {e_ref:.3e}, vs the torch module {e_torch:.3e} (|emb| = 20)")
+    assert e_ref <= TOL[mode] and e_torch <= TOL[mode]
+    with pytest.raises(RuntimeError, match="too many clips"):
+        m.audio_encode(torch.zeros(4, 1, 128, 204))
+
+
+def test_generate_with_raw_mel_through_the_hip_trunk():
+    from anyref_amd.audio import ImageBindAudio
+    from anyref_amd.model import AnyRefForCausalLM
+    cfg = config_tiny()
+    cfg.audio_trunk = AudioTrunkConfig(dim=64, blocks=2, heads=4)
+    sd = synth_state_dict(cfg, seed=41, scale=0.05)
+    trunk = ImageBindAudio(dim=64, blocks=2, heads=4, out_dim=cfg.audio_dim).eval()
+    pre = "model.audio_encoder."
+    trunk.load_state_dict({k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}, strict=True)
+    g = torch.Generator().manual_seed(42)
+    clip = torch.randn(1, 3, 224, 224, generator=g)
+    sam = torch.randn(1, 3, 224, 224, generator=g)
+    body = torch.randint(3, 980, (12,), generator=g)
+    ids = torch.cat([torch.tensor([1, IMAGE_TOKEN_INDEX]), body[:3], torch.full((3,), AUDIO_REF_INDEX), body[3:]])
+    mel = torch.randn(1, 3, 1, 128, 204, generator=g)
+    _, emb = trunk.get_audio_feature(mel)
+    sizes, H, W = [(224, 200)], [180], [160]
+    with torch.no_grad():
+        r0 = O.anyref_generate(sd, cfg, clip, [ids], sam, sizes, H, W, audio_embeds=[emb[0]], max_new_tokens=4, eos=False)
+        cfg.seg_token_idx = int(r0["output_ids"][0][-2])
+        ref = O.anyref_generate(sd, cfg, clip, [ids], sam, sizes, H, W, audio_embeds=[emb[0]], max_new_tokens=5, eos=False)
+    m = AnyRefForCausalLM.from_state_dict(cfg, {k: v.cuda() for k, v in sd.items()}, mode="parity", max_batch=1, max_seg=8)
+    m.config.eos_token_id = None
+    got_emb = m.audio_encode(mel).cpu()
+    assert (got_emb - emb[0]).abs().max().item() < 1e-3
+    (out_ids, masks, _), ex = m.generate(clip, ids[None], sam, sizes, H, W, audios=[mel], max_new_tokens=5, _return_extras=True)
+    want = ref["output_ids"][0]
+    assert out_ids[0].cpu().tolist() == want.tolist(), "greedy ids differ"
+    n = ref["hidden"][0].shape[0]
+    assert (ex["hidden"][0, :n].cpu() - ref["hidden"][0]).abs().max().item() < 2e-4
+    assert (masks[0].cpu() - ref["pred_masks"][0]).abs().max().item() <= 1e-3

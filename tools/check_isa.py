@@ -3,7 +3,7 @@
 
   * no kernel may use scratch (private segment): a kernel with register spills returned wrong,
     run-to-run different results from a hipGraph replay / beside a second stream on this stack
-    ("Compiler / runtime hazards"); launch_decode_layers also refuses such a kernel at run time
+    (DESIGN.md, "Compiler / runtime hazards")
   * the LDS-DMA GEMM must not wait vmcnt(0) in front of a tile's first ds_read (Makefile note on gemm.o)
 
 usage: python tools/check_isa.py    (compiles anyref_amd/csrc/*.hip to assembly under /tmp)
@@ -25,8 +25,8 @@ def asm_of(src, strict):
 
 def main():
     bad = 0
-    allowed_scratch = ("decode_layers_kernel",)  # refused at run time when it spills (decode.hip)
-    for src in ("gemm.hip", "attention.hip", "decode.hip", "ops.hip"):
+    allowed_scratch = ()
+    for src in ("gemm.hip", "attention.hip", "ops.hip"):
         s = asm_of(src, strict=(src == "gemm.hip"))
         for name, seg in re.findall(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)", s):
             if int(seg) > 0 and not any(a in name for a in allowed_scratch):
