@@ -65,8 +65,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="c2", choices=["c2", "c5", "tiny"],
-                    help="c2: BASELINE configs[1] (the headline); c5: 13B LLM, fp8 weights, batch 8 (configs[4]); tiny: plumbing")
+    ap.add_argument("--config", default="c2", choices=["c2", "c4", "c5", "tiny"],
+                    help="c2: BASELINE configs[1] (the headline); c4: c2 + audio reference (raw mel clips through the ImageBind "
+                         "trunk, configs[3]); c5: 13B LLM, fp8 weights, batch 8 (configs[4]); tiny: plumbing")
+    ap.add_argument("--audio-trunk", default="hip", choices=["hip", "torch"],
+                    help="c4: ImageBind audio trunk inside the HIP handle (f-4) or as the PyTorch-ROCm module")
     ap.add_argument("--mode", default=None, choices=["perf", "perf_fp8w"], help="default: perf (bf16); c5: perf_fp8w")
     ap.add_argument("--batch-per-gpu", type=int, default=1)
     ap.add_argument("--max-new-tokens", type=int, default=10)
@@ -98,10 +101,15 @@ def main():
 
     B, T = args.batch_per_gpu, args.max_new_tokens
     mode = args.mode or ("perf_fp8w" if args.config == "c5" else "perf")
-    if args.config == "c2":
+    if args.config in ("c2", "c4"):
         cfg = config_7b()
         cfg.llm.max_seq = 512
         S_img = 1024
+        if args.config == "c4":
+            args.no_cpu_baseline = True      # the CPU baseline / parity legs are quoted on C2
+            if args.audio_trunk == "hip":
+                from anyref_amd.config import AudioTrunkConfig
+                cfg.audio_trunk = AudioTrunkConfig()
     elif args.config == "c5":
         from anyref_amd.config import config_13b
         cfg = config_13b()
@@ -118,13 +126,24 @@ def main():
     clip, sam, ids = make_inputs(cfg, B, seed=1 + rank)
     clip, sam = clip.to(dev), sam.to(dev)                                          # resident in HBM
     sizes, H, W = [(S_img, S_img)] * B, [S_img] * B, [S_img] * B
+    gen_kw = {}
+    if args.config == "c4":
+        # AVSBench-style prompt: 3 <audio_ref> placeholders (utils/avsbench.py:256-259), raw mel clips [1,3,1,128,204]
+        from anyref_amd.config import AUDIO_REF_INDEX
+        ids = torch.cat([ids[:, :5], torch.full((B, 3), AUDIO_REF_INDEX), ids[:, 5:-3]], 1)
+        mels = [torch.randn(1, 3, 1, 128, 204, generator=torch.Generator().manual_seed(9 + b)).to(dev) for b in range(B)]
+        gen_kw["audios"] = mels
     model = AnyRefForCausalLM.from_state_dict(cfg, sd, mode=mode, device=local, max_batch=B, max_seg=2)
     model.config.eos_token_id = None                                               # fixed work: T new tokens
+    if args.config == "c4" and args.audio_trunk == "torch":
+        from anyref_amd.audio import ImageBindAudio
+        torch.manual_seed(0)
+        model.audio_encoder = ImageBindAudio().eval().to(dev)
     torch.cuda.synchronize()
     log(f"[bench] weights + perf model ready in {time.time() - t0:.1f}s, {model.device_bytes / 2**30:.1f} GiB on device")
 
     # name the id the random model emits at decode step 3 as [SEG]
-    out_ids, _, _ = model.generate(clip, ids, sam, sizes, H, W, max_new_tokens=T)
+    out_ids, _, _ = model.generate(clip, ids, sam, sizes, H, W, max_new_tokens=T, **gen_kw)
     seg_id = int(out_ids[0, ids.shape[1] + 2])
     model.set_seg_token_idx(seg_id)
 
@@ -132,7 +151,7 @@ def main():
     Lout = ids.shape[1] + T
 
     def step():
-        (oids, masks, _), ex = model.generate(clip, ids, sam, sizes, H, W, max_new_tokens=T, _return_extras=True)
+        (oids, masks, _), ex = model.generate(clip, ids, sam, sizes, H, W, max_new_tokens=T, _return_extras=True, **gen_kw)
         if world > 1:
             idp = torch.zeros(B, Lout, dtype=torch.long, device=dev)
             idp[:, : oids.shape[1]] = oids
@@ -215,6 +234,10 @@ def main():
             k: dict(launches_per_step=table[k]["count"], avg_launch_us=round(v["ms"] * 1e3 / v["count"], 2),
                     achieved=round(rate(v), 1), algorithmic_bytes_per_launch=round(v["bytes"] / v["count"]))
             for k, v in sorted(timed.items())}
+        roofline["note"] = ("frac = live hipEvent brackets in the timed region, where the SAM encoder co-runs on the second stream "
+                            "and inflates the GEMVs; rocprofv3 serialises the two streams (profiles/r02_overlap_under_rocprof.txt: "
+                            "<1 % of GEMV launches overlap another queue's kernel), so its per-kernel averages "
+                            "(profiles/r02_*kernel_stats.csv) check `isolated`, not the in-situ figure")
         if iso:
             ti = total(iso)
             roofline["isolated"] = {"achieved": round(rate(ti), 1), "frac": round(rate(ti) / peak, 4),
@@ -238,7 +261,8 @@ def main():
         table.items(), key=lambda kv: -kv[1]["ms"])}
 
     res = {
-        "metric": {"c2": "images/sec (1024^2, 7B LLM+ViT-L+SAM-H)", "c5": "images/sec (1024^2, 13B LLM+ViT-L+SAM-H, fp8 weights)",
+        "metric": {"c2": "images/sec (1024^2, 7B LLM+ViT-L+SAM-H)",
+                   "c4": "images/sec (1024^2, 7B LLM+ViT-L+SAM-H, audio-referred: ImageBind audio trunk + 3 audio tokens)", "c5": "images/sec (1024^2, 13B LLM+ViT-L+SAM-H, fp8 weights)",
                    "tiny": "images/sec (tiny plumbing config)"}[args.config],
         "value": round(ips, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
@@ -246,6 +270,9 @@ def main():
         "data": "synthetic",
         "config": {"workload": {"c2": "C2: LLaVA-7B + CLIP ViT-L/14 + SAM-H refer-seg forward, 1024x1024, S=320 prompt, "
                                       f"{T} new tokens, KV cache",
+                                "c4": "C4: C2 + audio reference: 3 raw mel clips [1,3,1,128,204] -> ImageBind audio trunk "
+                                      f"({'HIP, inside the handle' if args.audio_trunk == 'hip' else 'PyTorch-ROCm module'}) -> "
+                                      f"audio_projector -> 3 <audio_ref> slots; S=320 prompt, {T} new tokens, KV cache",
                                 "c5": "C5: 13B LLM + CLIP ViT-L/14 + SAM-H refer-seg forward, fp8-weight LLM, 1024x1024, S=320 "
                                       f"prompt, {T} new tokens, KV cache",
                                 "tiny": "C1 tiny plumbing config"}[args.config],
