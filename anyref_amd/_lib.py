@@ -8,6 +8,9 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+import torch  # noqa: F401  -- BEFORE the library: torch brings its own HIP runtime, and a process that loads
+# libanyref_hip.so (and with it /opt/rocm's runtime) first ends with "no HIP device visible" in anyref_create
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libanyref_hip.so")
 
