@@ -140,6 +140,9 @@ class Model : public ModelBase {
     if (ev_fork_) (void)hipEventDestroy(ev_fork_);
     if (ev_sam_) (void)hipEventDestroy(ev_sam_);
     if (next_host_) (void)hipHostFree(next_host_);
+    if (stage_) (void)hipHostFree(stage_);
+    for (auto e : ev_tok_)
+      if (e) (void)hipEventDestroy(e);
   }
   const char* mode_name() const override { return sizeof(T) == 2 ? (fp8w_ ? "bf16+fp8w" : "bf16") : "f32"; }
   void finalize() override;
@@ -329,7 +332,12 @@ class Model : public ModelBase {
   int64_t *ids_dev_ = nullptr, *next_dev_ = nullptr;
   int *lens_dev_ = nullptr, *slen_dev_ = nullptr, *pos_dev_ = nullptr, *kvlen_dev_ = nullptr, *rowmap_dev_ = nullptr,
       *idx_a_ = nullptr, *idx_b_ = nullptr;
-  int64_t* next_host_ = nullptr;  // pinned
+  int64_t* next_host_ = nullptr;  // pinned, two slots of max_batch tokens (the greedy loop runs one step ahead)
+  hipEvent_t ev_tok_[2] = {nullptr, nullptr};
+  // pinned int staging for the small index vectors a call uploads (no host wait for a pageable copy to drain).
+  // One region per purpose; a region is rewritten only after a later stream sync of the same or the next call.
+  int* stage_ = nullptr;
+  int *stage_first_ = nullptr, *stage_extra_ = nullptr, *stage_seg_ = nullptr, *stage_kl_ = nullptr;
 
   // ---- ImageBind audio trunk (f-4; present iff cfg.aud_blocks > 0) ----
   struct AudBlock {
@@ -617,7 +625,16 @@ void Model<T>::finalize() {
     rowmap_dev_ = talloc<int>(MB);
     idx_a_ = talloc<int>((size_t)MB * std::max(c.max_seg, 64));
     idx_b_ = talloc<int>((size_t)MB * std::max(c.max_seg, 64));
-    HIP_TRY(hipHostMalloc((void**)&next_host_, sizeof(int64_t) * MB));
+    HIP_TRY(hipHostMalloc((void**)&next_host_, sizeof(int64_t) * MB * 2));
+    for (auto& e : ev_tok_) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    {
+      const int n_first = 3 * MB, n_extra_max = 2 * MB * std::max(c.max_seg, 64), n_seg = 2 * MB * c.max_seg;
+      HIP_TRY(hipHostMalloc((void**)&stage_, sizeof(int) * (size_t)(n_first + n_extra_max + n_seg + MB)));
+      stage_first_ = stage_;
+      stage_extra_ = stage_first_ + n_first;
+      stage_seg_ = stage_extra_ + n_extra_max;
+      stage_kl_ = stage_seg_ + n_seg;
+    }
     if (c.rephrase_weight > 0.f) ensure_q_last();
   }
   // ================= glue =================
@@ -1435,17 +1452,16 @@ int Model<T>::splice_inputs(hipStream_t s, const int64_t* input_ids, const int32
   launch_embed_splice(ids_dev_, lens_dev_, B, Lmax, emb_table_, sizeof(T) == 2, c.llm_vocab, img_feat_, n_img, l_x_, Sp,
                       H, slen_dev_, s);
   if (n_extra > 0) {
-    std::vector<int> eb(n_extra), ep(n_extra);
+    if (n_extra > (int)cfg.max_batch * std::max(cfg.max_seg, 64)) throw std::runtime_error("too many extra slots");
+    int *eb = stage_extra_, *ep = stage_extra_ + n_extra;  // pinned: the copies below need no host wait
     for (int i = 0; i < n_extra; ++i) {
       const int b = extra_slots[2 * i], p = extra_slots[2 * i + 1];
       if (b < 0 || b >= B || p < 0 || p >= lens[b]) throw std::runtime_error("extra slot out of range");
       eb[i] = b;
       ep[i] = (img_pos[b] >= 0 && p > img_pos[b]) ? p + n_img - 1 : p;
     }
-    if (n_extra > (int)cfg.max_batch * std::max(cfg.max_seg, 64)) throw std::runtime_error("too many extra slots");
-    HIP_TRY(hipMemcpyAsync(idx_a_, eb.data(), n_extra * 4, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(idx_b_, ep.data(), n_extra * 4, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipStreamSynchronize(s));  // eb/ep are stack-backed
+    HIP_TRY(hipMemcpyAsync(idx_a_, eb, n_extra * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(idx_b_, ep, n_extra * 4, hipMemcpyHostToDevice, s));
     launch_scatter_rows(extra_embeds, idx_a_, idx_b_, n_extra, l_x_, Sp, H, s);
   }
   return Sp;
@@ -1496,9 +1512,12 @@ void Model<T>::run_tail(hipStream_t s, const float* sam_images, int B, const std
   }
   if (off > out_masks_cap) throw std::runtime_error("out_masks capacity too small");
   if (nseg == 0) return;
-  HIP_TRY(hipMemcpyAsync(idx_a_, seg_b.data(), nseg * 4, hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemcpyAsync(idx_b_, seg_pos.data(), nseg * 4, hipMemcpyHostToDevice, s));
-  HIP_TRY(hipStreamSynchronize(s));
+  for (int i = 0; i < nseg; ++i) {
+    stage_seg_[i] = seg_b[i];
+    stage_seg_[nseg + i] = seg_pos[i];
+  }
+  HIP_TRY(hipMemcpyAsync(idx_a_, stage_seg_, nseg * 4, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(idx_b_, stage_seg_ + nseg, nseg * 4, hipMemcpyHostToDevice, s));
   launch_gather_rows(hidden_all_, S, H, idx_a_, idx_b_, nseg, seg_h_, s);
   if (c.rephrase_weight > 0.f) {
     // anyref.py:735-755,767-769: the first [SEG] of image i gets + w * sum_j attn_j * hidden_j
@@ -1515,9 +1534,8 @@ void Model<T>::run_tail(hipStream_t s, const float* sam_images, int B, const std
         HIP_TRY(hipMemcpyAsync(attn_row_ + (size_t)b * S, attn_given + ((size_t)b * attn_n + e0) * attn_n,
                                (size_t)attn_n * 4, hipMemcpyDeviceToDevice, s));
       } else {
-        const int kl = e0 + 1;
-        HIP_TRY(hipMemcpyAsync(kvlen_dev_ + b, &kl, 4, hipMemcpyHostToDevice, s));
-        HIP_TRY(hipStreamSynchronize(s));
+        stage_kl_[b] = e0 + 1;
+        HIP_TRY(hipMemcpyAsync(kvlen_dev_ + b, stage_kl_ + b, 4, hipMemcpyHostToDevice, s));
         launch_attn_row_mean<T>(q_last_ + ((size_t)b * S + e0) * H, 0, hd, kc + (size_t)b * S * H, 0, H, hd,
                                 kvlen_dev_ + b, 1, nh, hd, 1.f / sqrtf((float)hd), attn_row_ + (size_t)b * S, S, s);
       }
@@ -1574,15 +1592,15 @@ void Model<T>::generate(hipStream_t s, const float* clip_images, const float* sa
   fork_sam(s, sam_images, B);
   // first token: logits of the last prompt row of every sequence
   {
-    std::vector<int> bb(B), pp(B);
+    int *bb = stage_first_, *pp = stage_first_ + B, *sl = stage_first_ + 2 * B;
     for (int b = 0; b < B; ++b) {
       bb[b] = b;
       pp[b] = slen[b] - 1;
+      sl[b] = slen[b];
     }
-    HIP_TRY(hipMemcpyAsync(idx_a_, bb.data(), B * 4, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(idx_b_, pp.data(), B * 4, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(pos_dev_, slen.data(), B * 4, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipMemcpyAsync(idx_a_, bb, B * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(idx_b_, pp, B * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(pos_dev_, sl, B * 4, hipMemcpyHostToDevice, s));
     launch_gather_rows(hidden_all_, S, H, idx_a_, idx_b_, B, l_xlast_, s);
     GemvArgs h;
     h.x = l_xlast_; h.ldx = H; gemv_w(h, lm_head_); h.y = l_logits_; h.ldy = c.llm_vocab; h.B = B; h.N = c.llm_vocab;
@@ -1593,19 +1611,28 @@ void Model<T>::generate(hipStream_t s, const float* clip_images, const float* sa
   // greedy loop (HF greedy search: stop a row at EOS, pad finished rows; anyref.py:704-716)
   std::vector<std::vector<int64_t>> gen(B);
   std::vector<char> fin(B, 0);
+  // With an EOS id the host must see token k before it may queue step k + 1 (a step queued past the EOS would be a
+  // whole wasted pass over the weights).  Without one (fixed-length generation) nothing depends on the token's
+  // value: its copy and an event are queued, THEN the next step, and the host waits for the event while the device
+  // already runs that step -- no host round trip between steps.
+  const bool ahead = eos_token_id < 0;
   for (int step = 0; step < max_new_tokens; ++step) {
-    HIP_TRY(hipMemcpyAsync(next_host_, next_dev_, B * 8, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    int64_t* tok = next_host_ + (size_t)(step & 1) * c.max_batch;
+    const bool last = step == max_new_tokens - 1;
+    HIP_TRY(hipMemcpyAsync(tok, next_dev_, B * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipEventRecord(ev_tok_[step & 1], s));
+    if (ahead && !last) decode_step_graph(s, B, keep_q);
+    HIP_TRY(hipEventSynchronize(ev_tok_[step & 1]));
     bool all = true;
     for (int b = 0; b < B; ++b) {
       if (!fin[b]) {
-        gen[b].push_back(next_host_[b]);
-        if (eos_token_id >= 0 && next_host_[b] == eos_token_id) fin[b] = 1;
+        gen[b].push_back(tok[b]);
+        if (eos_token_id >= 0 && tok[b] == eos_token_id) fin[b] = 1;
       }
       all = all && fin[b];
     }
-    if (all || step == max_new_tokens - 1) break;
-    decode_step_graph(s, B, keep_q);
+    if (all || last) break;
+    if (!ahead) decode_step_graph(s, B, keep_q);
   }
   const int Lout = Lmax + max_new_tokens;
   std::vector<int> seg_b, seg_pos, reph(B, 0);
