@@ -148,3 +148,64 @@ def test_adapter_errors(tmp_path):
                os.path.join(d, "adapter_model.bin"))
     with pytest.raises(ValueError, match="unpaired"):
         merge_lora({}, d)
+
+
+def test_hf_dir_layouts_and_peft_key_forms(tmp_path):
+    """sharded `.bin` with an index, a single safetensors file, a merged checkpoint (merge_lora.py:62) that already
+    carries the towers, and the key spellings peft versions write for `modules_to_save` / adapter names"""
+    from anyref_amd.checkpoint import read_hf_dir, merge_lora, _strip_peft_key
+    d = str(tmp_path / "bin")
+    os.makedirs(d)
+    a, b = {"x.weight": torch.arange(6.0).reshape(2, 3)}, {"y.weight": torch.ones(4)}
+    torch.save(a, os.path.join(d, "pytorch_model-00001-of-00002.bin"))
+    torch.save(b, os.path.join(d, "pytorch_model-00002-of-00002.bin"))
+    json.dump(dict(weight_map={"x.weight": "pytorch_model-00001-of-00002.bin", "y.weight": "pytorch_model-00002-of-00002.bin"}),
+              open(os.path.join(d, "pytorch_model.bin.index.json"), "w"))
+    got = read_hf_dir(d)
+    assert torch.equal(got["x.weight"], a["x.weight"]) and torch.equal(got["y.weight"], b["y.weight"])
+    d2 = str(tmp_path / "st")
+    os.makedirs(d2)
+    save_file({"z": torch.zeros(3)}, os.path.join(d2, "model.safetensors"))
+    assert list(read_hf_dir(d2)) == ["z"]
+    with pytest.raises(FileNotFoundError):
+        read_hf_dir(str(tmp_path))
+    k = _strip_peft_key("base_model.model.model.layers.0.self_attn.q_proj.lora_A.default.weight")
+    assert k == "model.layers.0.self_attn.q_proj.lora_A.weight"
+    assert _strip_peft_key("base_model.model.lm_head.modules_to_save.default.weight") == "lm_head.weight"
+    assert _strip_peft_key("base_model.model.model.text_hidden_fcs.0.0.weight") == "model.text_hidden_fcs.0.0.weight"
+    # fan_in_fan_out adapters store the transpose; original_module copies are ignored
+    ad = str(tmp_path / "ad")
+    os.makedirs(ad)
+    json.dump(dict(r=2, lora_alpha=4, fan_in_fan_out=True), open(os.path.join(ad, "adapter_config.json"), "w"))
+    A, Bm = torch.randn(2, 5), torch.randn(3, 2)
+    torch.save({"base_model.model.m.lora_A.default.weight": A, "base_model.model.m.lora_B.default.weight": Bm,
+                "base_model.model.head.original_module.weight": torch.zeros(1),
+                "base_model.model.head.modules_to_save.default.weight": torch.full((2,), 7.0)},
+               os.path.join(ad, "adapter_model.bin"))
+    sd = {"m.weight": torch.zeros(5, 3), "head.weight": torch.zeros(2)}
+    stats = merge_lora(sd, ad)
+    assert stats == {"lora_pairs": 1, "modules_to_save": 1}
+    assert torch.allclose(sd["m.weight"], ((Bm @ A) * 2.0).t()) and sd["head.weight"].tolist() == [7.0, 7.0]
+
+
+def test_merged_checkpoint_needs_no_initialize(tmp_path):
+    """`merge_lora.py:62` saves the merged model with `save_pretrained`: its directory holds every tensor under the
+    reference's names and a config that already has `train_mask_decoder`; `from_pretrained` alone is complete."""
+    from anyref_amd.checkpoint import missing_for
+    from anyref_amd.model import AnyRefForCausalLM
+    cfg = config_tiny()
+    sd = synth_state_dict(cfg, seed=5, scale=0.05)
+    d = str(tmp_path / "merged")
+    os.makedirs(d)
+    l = cfg.llm
+    json.dump(dict(hidden_size=l.dim, intermediate_size=l.mlp, num_hidden_layers=l.layers, num_attention_heads=l.heads,
+                   vocab_size=l.vocab, rms_norm_eps=l.rms_eps, train_mask_decoder=True, out_dim=256),
+              open(os.path.join(d, "config.json"), "w"))
+    save_file({k: v.contiguous() for k, v in sd.items()}, os.path.join(d, "model.safetensors"))
+    m = AnyRefForCausalLM.from_pretrained(d, torch_dtype=torch.float16, seg_token_idx=999, vision_pretrained="x/sam_vit_h.pth")
+    assert m.cfg.sam.dim == 1280 and m.cfg.sam.depth == 32          # sized from the name, weights from the checkpoint
+    m.get_model().initialize_vision_modules(m.get_model().config)    # both no-ops on a merged checkpoint
+    got = m.host_state_dict()
+    assert all(torch.equal(got[k], v) for k, v in sd.items())
+    tiny = config_tiny()
+    assert missing_for(tiny, got.keys(), audio=True) == []

@@ -257,11 +257,13 @@ def test_decode_mfma_path_batch_gt4(mode):
             with torch.no_grad():
                 ref = O.anyref_generate(sd_ref, cfg, clip[b:b + 1], [ids[b]], sam[b:b + 1], sizes[:1], H[:1], W[:1],
                                         max_new_tokens=8, eos=False)
-            if o6[b, : len(ids[b]) + 8].cpu().tolist() == ref["output_ids"][0].tolist():
-                herr = (ex6["hidden"][b, :n].cpu() - ref["hidden"][0][:n]).abs().max().item()
-                hscale = ref["hidden"][0].abs().max().item()
-                print(f"[{mode}] B=6 row {b}: hidden max-abs-err {herr:.3e} (scale {hscale:.2f})")
-                assert herr < PERF_HIDDEN_REL * hscale, f"row {b}: hidden err vs oracle {herr}"
+            # prompt rows (prefill) are comparable whatever the greedy path does; the decode rows only along the same ids
+            same = o6[b, : len(ids[b]) + 8].cpu().tolist() == ref["output_ids"][0].tolist()
+            n_cmp = n if same else len(ids[b]) + cfg.clip.n_patches - 1
+            herr = (ex6["hidden"][b, :n_cmp].cpu() - ref["hidden"][0][:n_cmp]).abs().max().item()
+            hscale = ref["hidden"][0].abs().max().item()
+            print(f"[{mode}] B=6 row {b}: hidden max-abs-err {herr:.3e} over {n_cmp} rows (scale {hscale:.2f}), ids identical: {same}")
+            assert herr < PERF_HIDDEN_REL * hscale, f"row {b}: hidden err vs oracle {herr}"
 
 
 @pytest.mark.parametrize("mode,B", [("parity", 1), ("perf", 1), ("perf", 4), ("perf", 8), ("parity", 4)])
