@@ -586,11 +586,12 @@ class AnyRefForCausalLM:
         offs = torch.zeros(B, dtype=torch.long)
         cap = sum(self.max_seg * h * w for h, w in zip(height, width))
         out_masks = torch.empty(cap, device=self.device, dtype=torch.float32)
-        L = 4 * self.cfg.sam.grid
-        out_low = torch.zeros(B, self.max_seg, L, L, device=self.device, dtype=torch.float32)
-        hid = None
-        if _return_extras:
-            hid = torch.empty(B, self.cfg.llm.max_seq, self.cfg.llm.dim, device=self.device, dtype=torch.float32)
+        out_low = hid = None
+        if _return_extras:       # low-res logits (what a DP driver all-gathers) and, unless "low", the hidden states
+            L = 4 * self.cfg.sam.grid
+            out_low = torch.zeros(B, self.max_seg, L, L, device=self.device, dtype=torch.float32)
+            if _return_extras != "low":
+                hid = torch.empty(B, self.cfg.llm.max_seq, self.cfg.llm.dim, device=self.device, dtype=torch.float32)
         eos = self.config.eos_token_id if self.config.eos_token_id is not None else -1
         self._check(self.lib.anyref_generate(
             self.h, self._stream(), _ptr(clip), _ptr(sam), _ptr(ids), _ptr(lens), B, Lmax, _ptr(extra),

@@ -87,7 +87,7 @@ class DataParallelAnyRef:
             (ids, masks, rest), ex = m.generate(
                 clip_images[sl], input_ids[sl], sam_images[sl], sam_resized_sizes[sl], height[sl], width[sl],
                 audios=pick(audios), ref_images=pick(ref_images), max_new_tokens=max_new_tokens,
-                attention_masks=pick(attention_masks), _return_extras=True)
+                attention_masks=pick(attention_masks), _return_extras="low")
             if self.world == 1:
                 return ids, masks, rest
             low, nseg, lens = ex["low_res"], ex["nseg"].to(m.device), ex["out_lens"].to(m.device)

@@ -151,7 +151,10 @@ def main():
     Lout = ids.shape[1] + T
 
     def step():
-        (oids, masks, _), ex = model.generate(clip, ids, sam, sizes, H, W, max_new_tokens=T, _return_extras=True, **gen_kw)
+        if world == 1:
+            oids, masks, _ = model.generate(clip, ids, sam, sizes, H, W, max_new_tokens=T, **gen_kw)
+            return oids, masks
+        (oids, masks, _), ex = model.generate(clip, ids, sam, sizes, H, W, max_new_tokens=T, _return_extras="low", **gen_kw)
         if world > 1:
             idp = torch.zeros(B, Lout, dtype=torch.long, device=dev)
             idp[:, : oids.shape[1]] = oids
