@@ -412,7 +412,74 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs a) {
       else wait_vmcnt<N * LPT>();
     }
   };
+  // 256-row tiles (8 waves, 128 x 64 / 128 x 80 per wave): the K tile is worked off in four QUADRANT phases of the
+  // wave's output (rows i in {0,1} x columns j in {0,1}, order 00 01 11 10 so that one operand's fragments carry
+  // over), the fragments of phase p + 1 requested before the MFMAs of phase p, s_setprio 1 around every MFMA cluster
+  // (guide T5: keeps hipcc from drifting the MFMAs in among the LDS reads).  Lab (scratch/lab/gemm8_lab.hip,
+  // interleaved rounds): SAM qkv 44.4 -> 41.5 us, fc1-shaped 77 -> 73, 4096^3 +4 %, 8192^3 +3 %.
+  constexpr bool QUAD = BM == 256 && WM == 2 && !W8 && MI == 8 && NI == 4;  // (256 x 320: 104 fragment + 160 accumulator registers would spill)
+  auto compute_quad = [&](auto buf_c) {
+    constexpr int buf = decltype(buf_c)::value;
+    constexpr int MH = MI / 2, NH0 = NI / 2, NH1 = NI - NH0;
+    const char* Ab = smem + buf * TILEB;
+    const char* Wb = Ab + BM * ROWB;
+    short8 a0[2][MH], a1[2][MH], b0[2][NH0], b1[2][NH1];
+    auto lda = [&](auto i_c, short8 (&af)[2][MH]) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int f = 0; f < MH; ++f) {
+          const int row = wr * TM + (decltype(i_c)::value * MH + f) * 16 + (lane & 15), c = ks * 4 + (lane >> 4);
+          af[ks][f] = *reinterpret_cast<const short8*>(Ab + row * ROWB + ((c ^ ((row >> 1) & 7)) << 4));
+        }
+    };
+    auto ldw0 = [&]() {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int f = 0; f < NH0; ++f) {
+          const int row = wc * TN + f * 16 + (lane & 15), c = ks * 4 + (lane >> 4);
+          b0[ks][f] = *reinterpret_cast<const short8*>(Wb + row * ROWB + ((c ^ ((row >> 1) & 7)) << 4));
+        }
+    };
+    auto ldw1 = [&]() {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int f = 0; f < NH1; ++f) {
+          const int row = wc * TN + (NH0 + f) * 16 + (lane & 15), c = ks * 4 + (lane >> 4);
+          b1[ks][f] = *reinterpret_cast<const short8*>(Wb + row * ROWB + ((c ^ ((row >> 1) & 7)) << 4));
+        }
+    };
+    auto mma = [&](auto i_c, auto j_c, const short8 (&af)[2][MH], const auto& bf) {
+      constexpr int i = decltype(i_c)::value, j = decltype(j_c)::value, NH = j == 0 ? NH0 : NH1;
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int f = 0; f < MH; ++f)
+#pragma unroll
+          for (int h = 0; h < NH; ++h)
+            acc[i * MH + f][j * NH0 + h] =
+                __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ks][h], af[ks][f], acc[i * MH + f][j * NH0 + h], 0, 0, 0);  // C^T tile
+      __builtin_amdgcn_s_setprio(0);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    ldw0();
+    lda(I0(), a0);
+    ldw1();
+    mma(I0(), I0(), a0, b0);
+    lda(I1(), a1);
+    mma(I0(), I1(), a0, b1);
+    mma(I1(), I1(), a1, b1);
+    mma(I1(), I0(), a1, b0);
+  };
   auto compute = [&](auto buf_c) {
+    if constexpr (QUAD) {
+      compute_quad(buf_c);
+      return;
+    }
     constexpr int buf = decltype(buf_c)::value;
     const char* Ab = smem + buf * TILEB;
     const char* Wb = Ab + BM * ROWB;

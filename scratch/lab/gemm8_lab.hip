@@ -120,6 +120,130 @@ __global__ __launch_bounds__(512) void v4(GA a) {
     }
 }
 
+// V5: PERSISTENT tile loop.  One workgroup per CU walks its share of BM x BN tiles; the LDS-DMA ring (NS stages)
+// runs over the flat sequence of (tile, k-tile) steps, so the next tile's first K tiles are already landing while
+// this tile's epilogue converts and stores (stores are fire-and-forget): prologue and epilogue of every tile but
+// the first / last hide behind the neighbouring tile's main loop.  For K = 1280 (20 K tiles) those are 25 % of v3.
+template <int BM, int BN, int WM, int WN, int NS>
+__global__ __launch_bounds__(WM * WN * 64) void v5(GA a) {
+  constexpr int BK = 64, NW = WM * WN;
+  constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 16, NI = TN / 16;
+  constexpr int ROWB = BK * 2, TILEB = (BM + BN) * ROWB;
+  constexpr int RA = BM / (NW * 8), RW = BN / (NW * 8), LPT = RA + RW;
+  static_assert((NS - 2) * LPT + MI * NI <= 63 && BM % (NW * 8) == 0 && BN % (NW * 8) == 0, "shape / vmcnt range");
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave / WN, wc = wave % WN;
+  const int tiles_m = cdiv(a.M, BM), tiles_n = cdiv(a.N, BN), ntile = tiles_m * tiles_n;
+  const int nt = a.K / BK;
+  const int srow = lane >> 3, sp = lane & 7;
+  // tile id -> (m0, n0): consecutive ids walk down a column of tiles (same W panel), workgroups of one XCD
+  // (blockIdx % 8) take a contiguous chunk of ids
+  const int G = gridDim.x, per_x = G / 8, xcd = blockIdx.x % 8, wi = blockIdx.x / 8;
+  auto tile_of = [&](int i) {  // i-th tile of this workgroup, or -1
+    const int chunk = (ntile + 7) / 8;
+    const int id = xcd * chunk + i * per_x + wi;
+    return (i * per_x + wi < chunk && id < ntile) ? id : -1;
+  };
+  int my = 0;
+  while (tile_of(my) >= 0) ++my;
+  if (my == 0) return;
+  const int total = my * nt;
+  float4v acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = float4v{0, 0, 0, 0};
+  auto stage = [&](auto buf_c, int step) {
+    constexpr int buf = decltype(buf_c)::value;
+    const int id = tile_of(step / nt), t = step % nt;
+    const int m0 = (id % tiles_m) * BM, n0 = (id / tiles_m) * BN;
+    char* base = smem + buf * TILEB;
+#pragma unroll
+    for (int r = 0; r < RA; ++r) {
+      const int row = (r * NW + wave) * 8 + srow;
+      int gm = m0 + row; gm = gm < a.M ? gm : a.M - 1;
+      __builtin_amdgcn_global_load_lds((gas_ptr)(a.A + (int64_t)gm * a.K + ((sp ^ ((row >> 1) & 7)) << 3) + t * BK),
+                                       (las_ptr)(base + (r * NW + wave) * 8 * ROWB), 16, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+      const int row = (r * NW + wave) * 8 + srow;
+      int gn = n0 + row; gn = gn < a.N ? gn : a.N - 1;
+      __builtin_amdgcn_global_load_lds((gas_ptr)(a.W + (int64_t)gn * a.K + ((sp ^ ((row >> 1) & 7)) << 3) + t * BK),
+                                       (las_ptr)(base + BM * ROWB + (r * NW + wave) * 8 * ROWB), 16, 0, 0);
+    }
+  };
+  auto compute = [&](auto buf_c) {
+    constexpr int buf = decltype(buf_c)::value;
+    const char* Ab = smem + buf * TILEB;
+    const char* Wb = Ab + BM * ROWB;
+#pragma unroll
+    for (int ks = 0; ks < BK / 32; ++ks) {
+      short8 af[MI], bfr[NI];
+      const int c = ks * 4 + (lane >> 4);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) { const int row = wr * TM + i * 16 + (lane & 15); af[i] = *reinterpret_cast<const short8*>(Ab + row * ROWB + ((c ^ ((row >> 1) & 7)) << 4)); }
+#pragma unroll
+      for (int j = 0; j < NI; ++j) { const int row = wc * TN + j * 16 + (lane & 15); bfr[j] = *reinterpret_cast<const short8*>(Wb + row * ROWB + ((c ^ ((row >> 1) & 7)) << 4)); }
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    }
+  };
+  auto epilogue = [&](int id) {
+    const int m0 = (id % tiles_m) * BM, n0 = (id / tiles_m) * BN;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int m = m0 + wr * TM + i * 16 + (lane & 15), n = n0 + wc * TN + j * 16 + 4 * (lane >> 4);
+        if (m < a.M && n < a.N) {
+          const float4v v = acc[i][j];
+          const uint32_t lo = (uint32_t)f2bf(v[0]).x | ((uint32_t)f2bf(v[1]).x << 16), hi = (uint32_t)f2bf(v[2]).x | ((uint32_t)f2bf(v[3]).x << 16);
+          *reinterpret_cast<uint2*>(a.C + (int64_t)m * a.N + n) = make_uint2(lo, hi);
+        }
+        acc[i][j] = float4v{0, 0, 0, 0};
+      }
+  };
+  static_for(std::make_integer_sequence<int, NS - 1>{}, [&](auto b) { if (decltype(b)::value < total) stage(b, decltype(b)::value); });
+  for (int s0 = 0; s0 < total; s0 += NS) {
+    static_for(std::make_integer_sequence<int, NS>{}, [&](auto b) {
+      constexpr int B = decltype(b)::value;
+      const int st = s0 + B;
+      if (st < total) {
+        // stores of an epilogue sit in the same vmcnt queue as the DMAs: count DMAs only by waiting for everything older
+        // than the NS-2 youngest TILES' worth -- an epilogue's stores are older than those, so they are waited for too
+        // (lab shapes are multiples of the tile: every lane stores, so the MI * NI epilogue stores of the previous
+        //  step are an exact count and may stay in flight together with the NS-2 youngest tiles' DMAs)
+        const int behind = total - 1 - st;
+        if (behind >= NS - 2) {
+          if (st % nt == 0 && st > 0) wait_vm<(NS - 2) * LPT + MI * NI>(); else wait_vm<(NS - 2) * LPT>();
+        } else {
+          wait_vm<0>();
+        }
+        __builtin_amdgcn_s_barrier();
+        if (st + NS - 1 < total) stage(std::integral_constant<int, (B + NS - 1) % NS>(), st + NS - 1);
+        compute(b);
+        if (st % nt == nt - 1) epilogue(tile_of(st / nt));
+      }
+    });
+  }
+}
+
+template <typename K>
+static float run_grid(K kern, int grid, size_t lds, GA a, int iters, int threads) {
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, 0, a);
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  CK(hipEventRecord(e0, 0));
+  for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, 0, a);
+  CK(hipEventRecord(e1, 0)); CK(hipDeviceSynchronize());
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+  return ms / iters * 1e3f;
+}
+
 int main() {
   const int shapes[][3] = {{4096, 3840, 1280}, {4096, 5120, 1280}, {4096, 1280, 5120}, {4096, 4096, 4096}, {8192, 8192, 8192}};
   for (auto& sh : shapes) {
@@ -144,15 +268,18 @@ int main() {
       t[2] = fminf(t[2], run(v4<1, 0, 2>, 256, 256, L2, a1, it, 512));
       t[3] = fminf(t[3], run(v4<0, 1, 2>, 256, 256, L2, a1, it, 512));
       t[4] = fminf(t[4], run(v4<1, 1, 2>, 256, 256, L2, a1, it, 512));
+      t[5] = fminf(t[5], run_grid(v5<128, 256, 2, 4, 3>, 256, 3 * 384 * 128, a1, it, 512));
+      t[6] = fminf(t[6], run_grid(v5<256, 256, 2, 4, 2>, 256, 2 * 512 * 128, a1, it, 512));
+      t[7] = fminf(t[7], run_grid(v5<128, 128, 2, 4, 4>, 256, 4 * 256 * 128, a1, it, 512));
     }
     std::vector<uint16_t> h0((size_t)M * N), h1((size_t)M * N);
     run(v3<256, 256, 2, 4, 2>, 256, 256, L2, a0, 1, 512);
-    run(v4<1, 1, 2>, 256, 256, L2, a1, 1, 512);
+    run_grid(v5<128, 256, 2, 4, 3>, 256, 3 * 384 * 128, a1, 1, 512);
     CK(hipMemcpy(h0.data(), C0, h0.size() * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(h1.data(), C1, h1.size() * 2, hipMemcpyDeviceToHost));
     size_t bad = 0; for (size_t i = 0; i < h0.size(); ++i) bad += h0[i] != h1[i];
     const double fl = 2.0 * M * N * K;
-    printf("M=%5d N=%5d K=%5d | v3 %7.1f us %6.0f TF | v4 plain %7.1f  spread %7.1f  prio %7.1f  spread+prio %7.1f (%6.0f TF) | mismatch %zu\n",
-           M, N, K, t[0], fl / t[0] * 1e-6, t[1], t[2], t[3], t[4], fl / t[4] * 1e-6, bad);
+    printf("M=%5d N=%5d K=%5d | v3 %7.1f us %6.0f TF | v4 plain %7.1f  spread %7.1f  prio %7.1f  spread+prio %7.1f | v5 persistent 128x256/3 %7.1f  256x256/2 %7.1f  128x128/4 %7.1f | mismatch(v5) %zu\n",
+           M, N, K, t[0], fl / t[0] * 1e-6, t[1], t[2], t[3], t[4], t[5], t[6], t[7], bad);
     fflush(stdout);
     hipFree(A); hipFree(W); hipFree(C0); hipFree(C1);
   }
