@@ -100,6 +100,10 @@ class AnyRefForCausalLM:
                                       mm_vision_tower=kwargs.pop("vision_tower", "openai/clip-vit-large-patch14"))
         self.h = None
         self._finalized = False
+        # `generate` returns the 3-tuple the two north-star callers unpack (eval_referseg.py:136, eval_avs_object.py:137).
+        # The reference's success path itself returns 2 values (anyref.py:822), which is what eval_refer_inv.py:135 and
+        # eval_coco20i.py:142 unpack: set `model.success_arity = 2` for those scripts.
+        self.success_arity = 3
         # `from_pretrained` flow: weights are gathered on the host first (base checkpoint, CLIP tower, SAM file,
         # token-row resize, LoRA merge all happen BEFORE `.cuda()` in the callers) and go to HBM in one build
         self._host_sd: Optional[Dict[str, torch.Tensor]] = {} if defer else None
@@ -602,8 +606,15 @@ class AnyRefForCausalLM:
         for b in range(B):
             full[b, : out_lens[b]] = out_ids[b, : out_lens[b]]
         output_ids = full.to(self.device)
-        if int(out_nseg.sum()) == 0:                      # anyref.py:729-730
+        total = int(out_nseg.sum())
+        if total == 0:                                    # anyref.py:729-730
             res = (output_ids, None, (None, None, None))
+        elif self.cfg.rephrase_weight > 0 and total < B:  # (3-tuple in the reference too)
+            # anyref.py:739-744,763-765: with rephrase on, the reference indexes the flattened [SEG] list by sample; fewer
+            # [SEG] tokens than samples is its IndexError -> `no_mask` path: one all-zero [1, height[0], width[0]] mask per
+            # sample (the same tensor object bs times), whatever the other rows produced
+            z = torch.zeros((1, height[0], width[0]), device=self.device, dtype=torch.float32)
+            res = (output_ids, [z] * B, (None, None, None))
         else:
             pred_masks = []
             for b in range(B):
@@ -611,6 +622,8 @@ class AnyRefForCausalLM:
                 o = int(offs[b])
                 pred_masks.append(out_masks[o: o + n * h * w].view(n, h, w))
             res = (output_ids, pred_masks, (None, None, None))
+        if self.success_arity == 2 and res[1] is not None and total >= B:
+            res = res[:2]                                 # the reference's own success path (anyref.py:822)
         if _return_extras:
             return res, dict(out_lens=out_lens, nseg=out_nseg, low_res=out_low, hidden=hid)
         return res

@@ -121,6 +121,12 @@ def test_generate_batch_audio_eos_and_noseg():
     m.config.eos_token_id = eos
     o2, _, _ = m.generate(clip[:1], ids[0][None], sam[:1], sizes[:1], H[:1], W[:1], audios=aud[:1], max_new_tokens=5)
     assert o2.shape[1] == len(ids[0]) + 2 and int(o2[0, -1]) == eos
+    # the reference's own mixed return arity (anyref.py:822 vs :730), for the callers that unpack two values
+    m.config.eos_token_id = None
+    m.success_arity = 2
+    r2 = m.generate(clip[:1], ids[0][None], sam[:1], sizes[:1], H[:1], W[:1], audios=aud[:1], max_new_tokens=5)
+    assert len(r2) == 2 and r2[1] is not None
+    m.success_arity = 3
     # no [SEG] anywhere
     m2cfg = config_tiny()
     m2cfg.seg_token_idx = cfg.llm.vocab + 5
@@ -128,6 +134,28 @@ def test_generate_batch_audio_eos_and_noseg():
     m2.config.eos_token_id = None
     o3, masks3, rest = m2.generate(clip[:1], ids[0][None], sam[:1], sizes[:1], H[:1], W[:1], audios=aud[:1], max_new_tokens=3)
     assert masks3 is None and rest == (None, None, None)
+
+
+def test_rephrase_batch_with_fewer_segs_than_samples_takes_the_reference_no_mask_path():
+    """anyref.py:739-744,763-765: rephrase on, batch of 2, only one [SEG] in the whole batch -> zeros [1, h0, w0] x bs."""
+    from anyref_amd.model import AnyRefForCausalLM
+    cfg = config_tiny()
+    cfg.rephrase_weight = 0.5
+    sd = synth_state_dict(cfg, seed=7, scale=0.05)
+    clip, sam, ids = make_inputs(cfg, 2, seed=8)
+    sizes, H, W = [(224, 224)] * 2, [200, 224], [180, 224]
+    m = AnyRefForCausalLM.from_state_dict(cfg, {k: v.cuda() for k, v in sd.items()}, mode="parity", max_batch=2, max_seg=4)
+    m.config.eos_token_id = None
+    padded, mask = pad(ids)
+    o0, _, _ = m.generate(clip, padded, sam, sizes, H, W, max_new_tokens=5, attention_masks=mask)
+    # a [SEG] id that occurs exactly once in the whole batch (the search covers output_ids[:, 1:], prompts included):
+    # a prompt token of row 0 that neither row repeats
+    everything = o0[0, 1: len(ids[0]) + 5].tolist() + o0[1, 1: len(ids[1]) + 5].tolist()
+    seg = next(int(t) for t in ids[0][2:].tolist() if everything.count(int(t)) == 1)
+    m.set_seg_token_idx(seg)                          # exactly one [SEG], in row 0 only
+    out_ids, masks, rest = m.generate(clip, padded, sam, sizes, H, W, max_new_tokens=5, attention_masks=mask)
+    assert rest == (None, None, None) and len(masks) == 2
+    assert all(t.shape == (1, H[0], W[0]) and float(t.abs().sum()) == 0.0 for t in masks)
 
 
 def test_rephrase_and_teacher_forward():
