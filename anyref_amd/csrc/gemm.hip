@@ -1171,6 +1171,35 @@ void launch_gemv(const GemvArgs& a, hipStream_t s) {
   }
 }
 template void launch_gemv<float>(const GemvArgs&, hipStream_t);
+
+// Skinny f32 GEMMs of the mask decoder and the [SEG] hand-off (M <= 8 token rows, f32 weights in every mode)
+// through the weight-streaming kernel above: the 64 x 64 MFMA tile kernel runs them as 4-64 workgroups walking
+// K in 16-wide steps, a chain of dependent global-load round trips (text_hidden_fcs[0], 4096 x 4096 f32 = 64 MB
+// on 64 workgroups: 146 us; here every weight row is one wave's 16-byte loads and the grid covers the rows).
+void launch_gemv_skinny_f32(const GemvArgs& a, hipStream_t s) {
+  if (a.B < 1 || a.B > 8 || a.K > 4096 || a.K % 4 || a.W2 || a.w_fp8 || a.gain || ((uintptr_t)a.W & 15) ||
+      ((uintptr_t)a.x & 15) || a.ldx % 4)
+    throw std::runtime_error("gemv_skinny_f32: 1..8 rows, K <= 4096, K % 4 == 0, 16-byte aligned rows");
+  const int ngroups = cdiv(a.N, 2);
+  const int grid = ngroups >= 4096 ? 512 : cdiv(ngroups, 8);
+  auto go = [&](auto nb_tag) {
+    constexpr int NB = decltype(nb_tag)::value;
+    auto kern = &gemv_kernel<float, NB, false, 8>;
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                150 * 1024);
+      attr_set = true;
+    }
+    ProfScope prof("gemv_f32_skinny", 2.0 * a.B * a.N * (double)a.K, (double)a.N * a.K * 4 + (double)a.B * (a.K + a.N) * 4,
+                   s);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), (size_t)NB * a.K * sizeof(float), s, a, 0, a.B);
+  };
+  if (a.B == 1) go(std::integral_constant<int, 1>());
+  else if (a.B == 2) go(std::integral_constant<int, 2>());
+  else if (a.B <= 4) go(std::integral_constant<int, 4>());
+  else go(std::integral_constant<int, 8>());
+}
 template void launch_gemv<bf16>(const GemvArgs&, hipStream_t);
 
 }  // namespace anyref

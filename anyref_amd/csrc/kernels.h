@@ -126,6 +126,8 @@ struct GemvArgs {
 };
 template <typename T>
 void launch_gemv(const GemvArgs& a, hipStream_t s);
+// f32 weights, 1..8 activation rows, K <= 4096: the mask decoder's token GEMMs and the [SEG] hand-off MLP
+void launch_gemv_skinny_f32(const GemvArgs& a, hipStream_t s);
 // Row-wise fp8 (e4m3fn) weight quantisation: scale[n] = max|W[n,:]| / 448 (1 if the row is zero),
 // q[n,k] = RNE_e4m3(W[n,k] / scale[n]); src f32 [N, K] (row stride lds), q [N, K] bytes (row stride ldq)
 void launch_quant_fp8_rows(const float* src, int lds, int N, int K, uint8_t* q, int ldq, float* scale, hipStream_t s,

@@ -251,8 +251,17 @@ class Model : public ModelBase {
     l.ws = talloc<float>(n);
     return l;
   }
+  bool skinny_off_ = getenv("ANYREF_NO_SKINNY_GEMV") != nullptr;
   void gemmf(hipStream_t s, const float* A, int lda, const LinF& l, float* C, int ldc, int M, int act,
              const float* resid = nullptr, int ldr = 0) {
+    if (M >= 1 && M <= 8 && l.k <= 4096 && l.k % 4 == 0 && lda % 4 == 0 && !((uintptr_t)A & 15) && (!resid || ldr == ldc) &&
+        !skinny_off_) {
+      GemvArgs g;  // a handful of token rows: weight streaming, not a 64 x 64 tile walk (gemm.hip)
+      g.x = A; g.ldx = lda; g.W = l.w; g.bias = l.b; g.y = C; g.ldy = ldc; g.resid = resid; g.B = M; g.N = l.n;
+      g.K = l.k; g.act = act;
+      launch_gemv_skinny_f32(g, s);
+      return;
+    }
     GemmArgs a;
     a.A = A; a.lda = lda; a.W = l.w; a.ldw = l.k; a.bias = l.b; a.C = C; a.ldc = ldc; a.M = M; a.N = l.n;
     a.K = l.k; a.act = act; a.c_f32 = 1; a.resid = resid; a.ldr = ldr;
