@@ -1002,7 +1002,11 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int b0, int nb) {
       for (int i = 0; i < XPT; ++i) {
         const int k = tid + i * 512;
         if (k < K) {
-          xs[b * K + k] = from_f32<T>(xr[b][i] * scale * gr[i]);
+          const float v = xr[b][i] * scale * gr[i];
+          xs[b * K + k] = from_f32<T>(v);
+          // the normalised row itself is an output of the step (last-layer hidden state before lm_head)
+          if (a.xn_out && blockIdx.x == 0)
+            a.xn_out[(int64_t)(a.xn_row_map ? a.xn_row_map[b0 + b] : b0 + b) * a.xn_ld + k] = v;
         }
       }
     }

@@ -123,6 +123,10 @@ struct GemvArgs {
   const float* wscale = nullptr;
   const float* wscale2 = nullptr;
   int ws_stride = 1;
+  // optional f32 copy of the normalised input rows (needs `gain`): xn_out[(xn_row_map ? xn_row_map[b] : b) * xn_ld + k]
+  float* xn_out = nullptr;
+  const int* xn_row_map = nullptr;
+  int xn_ld = 0;
 };
 template <typename T>
 void launch_gemv(const GemvArgs& a, hipStream_t s);
@@ -271,6 +275,10 @@ template <typename T>
 void launch_swiglu(const void* gu, int M, int F, void* out, hipStream_t s);
 // argmax over f32 rows (first index on ties) -> i64
 void launch_argmax(const float* x, int M, int N, int ldx, int64_t* out, hipStream_t s, int* bump = nullptr);
+// argmax, pos[b] += 1, and the next decode step's inputs in the same launch: x_next[b] = table[argmax], row_map[b] =
+// b * maxS + pos[b], kvlen[b] = pos[b] + 1
+void launch_argmax_next(const float* x, int M, int N, int ldx, int64_t* out, int* pos, const void* table, int is_bf16,
+                        int D, int maxS, float* x_next, int* row_map, int* kvlen, hipStream_t s);
 // ConvTranspose2d k2s2 output un-shuffle (+ LayerNorm2d + GELU): tmp f32 [n*g*g, 4*C] (col = (dy*2+dx)*C+c)
 // -> out T [n*(2g)*(2g), C] NHWC
 template <typename T>

@@ -919,8 +919,9 @@ void Model<T>::finalize() {
     HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
     HIP_TRY(hipStreamCreateWithPriority(&s2_, hipStreamNonBlocking, least));
   }
-  HIP_TRY(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
-  HIP_TRY(hipEventCreateWithFlags(&ev_sam_, hipEventDisableTiming));
+  const unsigned ev_flags = getenv("ANYREF_JOIN_TIMING") ? hipEventDefault : hipEventDisableTiming;
+  HIP_TRY(hipEventCreateWithFlags(&ev_fork_, ev_flags));
+  HIP_TRY(hipEventCreateWithFlags(&ev_sam_, ev_flags));
   HIP_TRY(hipDeviceSynchronize());
   drop_raw();
   finalized_ = true;
@@ -1124,8 +1125,8 @@ void Model<T>::llm_decode_step(hipStream_t s, int B, bool keep_q) {
   // next_dev_ -> embed -> all layers at pos_dev_ -> hidden_all_[b,pos] -> logits -> next_dev_; pos += 1
   const anyref_config& c = cfg;
   const int H = c.llm_dim, F = c.llm_mlp, nh = c.llm_heads, hd = H / nh, S = c.llm_max_seq, nl = c.llm_layers;
-  launch_embed_rows(next_dev_, B, emb_table_, sizeof(T) == 2, H, d_x_, s);
-  launch_decode_index(pos_dev_, B, S, rowmap_dev_, kvlen_dev_, s);
+  // d_x_ (embedding of next_dev_), rowmap_dev_ and kvlen_dev_ were written by the launch that chose next_dev_
+  // (launch_argmax_next: the first-token argmax in generate(), then the tail of every step)
   // More than 4 sequences per call: the FMA GEMV would stream every weight twice (4 batch rows per pass) and
   // its VALU work grows with B, so the linears go through the MFMA GEMM (M = B rows of a 64/128-row tile,
   // split-K to fill the chip: weights are read once) with the norms / SwiGLU as in prefill.
@@ -1178,15 +1179,15 @@ void Model<T>::llm_decode_step(hipStream_t s, int B, bool keep_q) {
     d.x = d_act_; d.ldx = F; gemv_w(d, L.down); d.y = d_x_; d.resid = d_x_; d.ldy = H; d.B = B; d.N = H; d.K = F;
     launch_gemv<T>(d, s);
   }
-  NormArgs n;
-  n.x = d_x_; n.ldx = H; n.gain = llm_norm_.g; n.y = hidden_all_; n.ldy = H; n.M = B; n.D = H;
-  n.eps = c.llm_rms_eps; n.rms = 1; n.y_f32 = 1; n.row_map = rowmap_dev_;
-  launch_norm<T>(n, s);
+  // final RMSNorm inside the lm_head GEMV's input stage; its f32 rows are hidden_states[-1] of this position
   GemvArgs h;
   h.x = d_x_; h.ldx = H; h.gain = llm_norm_.g; h.eps = c.llm_rms_eps; gemv_w(h, lm_head_); h.y = l_logits_;
   h.ldy = c.llm_vocab; h.B = B; h.N = c.llm_vocab; h.K = H;
+  h.xn_out = hidden_all_; h.xn_row_map = rowmap_dev_; h.xn_ld = H;
   launch_gemv<T>(h, s);
-  launch_argmax(l_logits_, B, c.llm_vocab, c.llm_vocab, next_dev_, s, pos_dev_);  // and pos += 1
+  // argmax, pos += 1, and the next step's embedding row / cache row index / key count
+  launch_argmax_next(l_logits_, B, c.llm_vocab, c.llm_vocab, next_dev_, pos_dev_, emb_table_, sizeof(T) == 2, H, S, d_x_,
+                     rowmap_dev_, kvlen_dev_, s);
 }
 
 template <typename T>
@@ -1478,6 +1479,22 @@ int Model<T>::splice_inputs(hipStream_t s, const int64_t* input_ids, const int32
 
 template <typename T>
 void Model<T>::join_sam(hipStream_t s) {
+  static const bool timing = getenv("ANYREF_JOIN_TIMING") != nullptr;  // diagnostic: which stream the join waits for
+  if (sam_forked_ && timing) {
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, s));
+    HIP_TRY(hipStreamWaitEvent(s, ev_sam_, 0));
+    HIP_TRY(hipEventRecord(e1, s));
+    HIP_TRY(hipEventSynchronize(e1));
+    float wait_ms = 0.f, sam_ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&wait_ms, e0, e1));
+    HIP_TRY(hipEventElapsedTime(&sam_ms, ev_fork_, ev_sam_));
+    fprintf(stderr, "[anyref] join: main stream waited %.3f ms for the SAM encoder (fork -> done %.3f ms)\n", wait_ms, sam_ms);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+  }
   if (sam_forked_) HIP_TRY(hipStreamWaitEvent(s, ev_sam_, 0));  // everything after this on `s` sees the image embeddings
   sam_forked_ = false;
   sam_head_done_ = false;
@@ -1605,7 +1622,7 @@ void Model<T>::generate(hipStream_t s, const float* clip_images, const float* sa
     for (int b = 0; b < B; ++b) {
       bb[b] = b;
       pp[b] = slen[b] - 1;
-      sl[b] = slen[b];
+      sl[b] = slen[b] - 1;  // launch_argmax_next bumps it to the first generated position
     }
     HIP_TRY(hipMemcpyAsync(idx_a_, bb, B * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(idx_b_, pp, B * 4, hipMemcpyHostToDevice, s));
@@ -1615,7 +1632,8 @@ void Model<T>::generate(hipStream_t s, const float* clip_images, const float* sa
     h.x = l_xlast_; h.ldx = H; gemv_w(h, lm_head_); h.y = l_logits_; h.ldy = c.llm_vocab; h.B = B; h.N = c.llm_vocab;
     h.K = H;
     launch_gemv<T>(h, s);
-    launch_argmax(l_logits_, B, c.llm_vocab, c.llm_vocab, next_dev_, s);
+    launch_argmax_next(l_logits_, B, c.llm_vocab, c.llm_vocab, next_dev_, pos_dev_, emb_table_, sizeof(T) == 2, H, S, d_x_,
+                       rowmap_dev_, kvlen_dev_, s);
   }
   // greedy loop (HF greedy search: stop a row at EOS, pad finished rows; anyref.py:704-716)
   std::vector<std::vector<int64_t>> gen(B);

@@ -662,9 +662,20 @@ __device__ __forceinline__ void argmax_take(float v, int i, float& best, int& bi
     bi = i;
   }
 }
+// `nx` (optional): the decode step's bookkeeping for the NEXT step rides in the same launch -- embedding row of
+// the chosen token -> nx.x[b], KV-cache row index and key count of the (bumped) position -- instead of two more
+// one-workgroup launches at the head of every step.
+struct ArgmaxNext {
+  const void* table = nullptr;  // [vocab, D] bf16 or f32
+  int is_bf16 = 0, D = 0, maxS = 0;
+  float* x = nullptr;           // [B, D]
+  int* row_map = nullptr;       // [B] b * maxS + pos
+  int* kvlen = nullptr;         // [B] pos + 1
+};
 __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ x, int N, int ldx,
-                                                      int64_t* __restrict__ out, int* __restrict__ bump) {
-  constexpr int NT = 1024, U = 4;
+                                                      int64_t* __restrict__ out, int* __restrict__ bump,
+                                                      ArgmaxNext nx) {
+  constexpr int NT = 1024, U = 8;  // 8 x 1024 float4: a 32k-entry row in one round trip
   const float* row = x + (int64_t)blockIdx.x * ldx;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float best = -INFINITY;
@@ -707,12 +718,38 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ 
   if (tid == 0) {
     for (int w = 1; w < NT / 64; ++w) argmax_take(sv[w], si[w], best, bi);
     out[blockIdx.x] = bi;
-    if (bump) bump[blockIdx.x] += 1;
+    si[0] = bi;
+    if (bump) {
+      const int p = bump[blockIdx.x] + 1;
+      bump[blockIdx.x] = p;
+      if (nx.x) {
+        nx.row_map[blockIdx.x] = blockIdx.x * nx.maxS + p;
+        nx.kvlen[blockIdx.x] = p + 1;
+      }
+    }
+  }
+  if (!nx.x) return;
+  __syncthreads();
+  const int64_t id = si[0];
+  float* dst = nx.x + (int64_t)blockIdx.x * nx.D;
+  if (nx.is_bf16) {
+    const bf16* src = reinterpret_cast<const bf16*>(nx.table) + id * nx.D;
+    for (int d = tid; d < nx.D; d += NT) dst[d] = bf2f(src[d]);
+  } else {
+    const float* src = reinterpret_cast<const float*>(nx.table) + id * nx.D;
+    for (int d = tid; d < nx.D; d += NT) dst[d] = src[d];
   }
 }
 void launch_argmax(const float* x, int M, int N, int ldx, int64_t* out, hipStream_t s, int* bump) {
   if (M <= 0) return;
-  hipLaunchKernelGGL(argmax_kernel, dim3(M), dim3(1024), 0, s, x, N, ldx, out, bump);
+  hipLaunchKernelGGL(argmax_kernel, dim3(M), dim3(1024), 0, s, x, N, ldx, out, bump, ArgmaxNext{});
+}
+void launch_argmax_next(const float* x, int M, int N, int ldx, int64_t* out, int* pos, const void* table, int is_bf16,
+                        int D, int maxS, float* x_next, int* row_map, int* kvlen, hipStream_t s) {
+  if (M <= 0) return;
+  ArgmaxNext nx;
+  nx.table = table; nx.is_bf16 = is_bf16; nx.D = D; nx.maxS = maxS; nx.x = x_next; nx.row_map = row_map; nx.kvlen = kvlen;
+  hipLaunchKernelGGL(argmax_kernel, dim3(M), dim3(1024), 0, s, x, N, ldx, out, pos, nx);
 }
 
 // ---------------------------------------------------------------------------------------------
