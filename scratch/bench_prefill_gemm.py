@@ -6,6 +6,7 @@ P = lambda t: C.c_void_p(t.data_ptr())
 pad = int(os.environ.get("ANYREF_OPTEST_LDW_PAD", "0"))
 for M, N, K in [(320, 22016, 4096), (320, 12288, 4096), (320, 4096, 4096), (320, 4096, 11008)]:
     nb = max(2, int(600e6 // (N * K * 2)) + 1)     # rotate weights: cold in L2 / MALL like a real layer sweep
+    if os.environ.get("WARM"): nb = 1            # same weights every call: MALL-resident (256 MB)
     A = torch.randn(M, K, device='cuda').bfloat16()
     Ws = [(torch.randn(N, K + pad, device='cuda') * 0.05).bfloat16() for _ in range(nb)]
     Cc = torch.empty(M, N, device='cuda', dtype=torch.bfloat16)

@@ -346,6 +346,104 @@ __global__ __launch_bounds__(WM * WN * 64) void v3(GA a) {
     }
 }
 
+// ---------------- V6: W streamed global -> VGPR per wave (no LDS for the weight operand), A through LDS-DMA -------------
+// Skinny-M prefill shapes are bound by bytes in flight per CU (LDS capacity x latency): with the weight tiles in a
+// register ring only A occupies LDS, so NS can be 5-8 instead of 2-3.  NW waves, each owns TN = BN / NW columns.
+template <int BM, int BN, int NW, int NS, bool PACKED = false>
+__global__ __launch_bounds__(NW * 64) void v6(GA a) {
+  constexpr int BK = 64;
+  constexpr int TN = BN / NW, MI = BM / 16, NI = TN / 16;
+  constexpr int ROWB = BK * 2, TILEB = BM * ROWB;
+  constexpr int RA = BM / (NW * 8), LPT = RA + 2 * NI;
+  static_assert(BM % (NW * 8) == 0 && (NS - 2) * LPT <= 63, "tile / vmcnt range");
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_m = cdiv(a.M, BM), tiles_n = cdiv(a.N, BN), nwg = tiles_m * tiles_n;
+  int id = blockIdx.x;
+  { const int q = nwg / 8, r = nwg % 8, xcd = id % 8; id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + id / 8; }
+  const int m0 = (id % tiles_m) * BM, n0 = (id / tiles_m) * BN;   // M-fastest: the M tiles of a W panel are neighbours
+  float4v acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = float4v{0, 0, 0, 0};
+  const int srow = lane >> 3, sp = lane & 7;
+  const bf16* asrc[RA]; const bf16* wsrc[NI];
+#pragma unroll
+  for (int r = 0; r < RA; ++r) { const int row = (r * NW + wave) * 8 + srow; int gmr = m0 + row; gmr = gmr < a.M ? gmr : a.M - 1; asrc[r] = a.A + (int64_t)gmr * a.K + ((sp ^ ((row >> 1) & 7)) << 3); }
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    int gn = n0 + wave * TN + j * 16 + (lane & 15); gn = gn < a.N ? gn : a.N - 1;
+    if (PACKED) {  // timing probe: W as [N/16][K/32][64 lanes][8] fragments (results are wrong on row-major W)
+      int g16 = (n0 + wave * TN) / 16 + j; g16 = g16 < a.N / 16 ? g16 : a.N / 16 - 1;
+      wsrc[j] = a.W + ((int64_t)g16 * (a.K / 32) * 64 + lane) * 8;
+    } else wsrc[j] = a.W + (int64_t)gn * a.K + 8 * (lane >> 4);
+  }
+  short8 wreg[NS][2][NI];
+  auto stage = [&](auto buf_c, int t) {
+    constexpr int buf = decltype(buf_c)::value;
+    char* base = smem + buf * TILEB;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) wreg[buf][ks][j] = *reinterpret_cast<const short8*>(wsrc[j] + (PACKED ? (t * 2 + ks) * 512 : t * BK + ks * 32));
+#pragma unroll
+    for (int r = 0; r < RA; ++r) __builtin_amdgcn_global_load_lds((gas_ptr)(asrc[r] + t * BK), (las_ptr)(base + (r * NW + wave) * 8 * ROWB), 16, 0, 0);
+  };
+  auto compute = [&](auto buf_c) {
+    constexpr int buf = decltype(buf_c)::value;
+    const char* Ab = smem + buf * TILEB;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      short8 af[MI];
+      const int c = ks * 4 + (lane >> 4);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) { const int row = i * 16 + (lane & 15); af[i] = *reinterpret_cast<const short8*>(Ab + row * ROWB + ((c ^ ((row >> 1) & 7)) << 4)); }
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[buf][ks][j], af[i], acc[i][j], 0, 0, 0);
+    }
+  };
+  const int nt = a.K / BK;
+  static_for(std::make_integer_sequence<int, NS - 1>{}, [&](auto b) { stage(b, decltype(b)::value); });  // nt >= NS - 1 (host)
+  // steady state: whole groups of NS tiles with a tile to request for every one of them -- branch-free, so that the
+  // compiler's own vmcnt for the register ring is the exact count and not a conservative vmcnt(0) at a join
+  int t0 = 0;
+  for (; t0 + 2 * NS - 1 <= nt; t0 += NS) {
+    static_for(std::make_integer_sequence<int, NS>{}, [&](auto b) {
+      constexpr int B = decltype(b)::value;
+      wait_vm<(NS - 2) * LPT>();
+      __builtin_amdgcn_s_barrier();
+      stage(std::integral_constant<int, (B + NS - 1) % NS>(), t0 + B + NS - 1);
+      compute(b);
+    });
+  }
+  for (; t0 < nt; t0 += NS) {
+    static_for(std::make_integer_sequence<int, NS>{}, [&](auto b) {
+      constexpr int B = decltype(b)::value;
+      const int t = t0 + B;
+      if (t < nt) {
+        wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        if (t + NS - 1 < nt) stage(std::integral_constant<int, (B + NS - 1) % NS>(), t + NS - 1);
+        compute(b);
+      }
+    });
+  }
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int m = m0 + i * 16 + (lane & 15), n = n0 + wave * TN + j * 16 + 4 * (lane >> 4);
+      if (m < a.M && n < a.N) {
+        const float4v v = acc[i][j];
+        const uint32_t lo = (uint32_t)f2bf(v[0]).x | ((uint32_t)f2bf(v[1]).x << 16), hi = (uint32_t)f2bf(v[2]).x | ((uint32_t)f2bf(v[3]).x << 16);
+        *reinterpret_cast<uint2*>(a.C + (int64_t)m * a.N + n) = make_uint2(lo, hi);
+      }
+    }
+}
+
 template <typename K>
 static float run(K kern, int BM, int BN, size_t lds, GA a, int iters, int threads = 256) {
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -373,7 +471,7 @@ static float run_cold(K kern, int BM, int BN, size_t lds, GA a, const std::vecto
 }
 
 int main() {
-  const int shapes[][3] = {{320, 22016, 4096}, {320, 12288, 4096}, {320, 27648, 5120}};
+  const int shapes[][3] = {{320, 22016, 4096}, {320, 12288, 4096}, {320, 4096, 4096}, {320, 4096, 11008}};
   for (auto& sh : shapes) {
     const int M = sh[0], N = sh[1], K = sh[2];
     std::vector<uint16_t> hA((size_t)M * K), hW((size_t)N * K);
@@ -387,28 +485,33 @@ int main() {
     const int nW = (int)(700e6 / ((double)N * K * 2)) + 1;   // rotate weights past the 256 MiB Infinity Cache
     std::vector<bf16*> Ws(nW);
     for (auto& w : Ws) { CK(hipMalloc(&w, hW.size() * 2)); CK(hipMemcpy(w, hW.data(), hW.size() * 2, hipMemcpyHostToDevice)); }
-    const double fl = 2.0 * M * N * K;
     const int it = 40;
     GA a0{A, Ws[0], C0, M, N, K}, a1{A, Ws[0], C1, M, N, K};
-    const float a_ = run_cold(v2<128, 128, 2, 4>, 128, 128, 2 * 256 * 128, a0, Ws, it, 512);
-    const float b_ = run_cold(v3<128, 128, 2, 4, 2>, 128, 128, 2 * 256 * 128, a1, Ws, it, 512);
-    const float c_ = run_cold(v3<128, 128, 2, 4, 3>, 128, 128, 3 * 256 * 128, a1, Ws, it, 512);
-    const float d_ = run_cold(v3<128, 128, 2, 4, 4>, 128, 128, 4 * 256 * 128, a1, Ws, it, 512);
-    const float e_ = run_cold(v2<64, 256, 1, 4>, 64, 256, 2 * 320 * 128, a1, Ws, it, 256);
-    const float f_ = run_cold(v3<64, 256, 1, 4, 3>, 64, 256, 3 * 320 * 128, a1, Ws, it, 256);
-    const float g_ = run_cold(v3<64, 512, 1, 8, 2>, 64, 512, 2 * 576 * 128, a1, Ws, it, 512);
-    // check: v3 NS=4 (last to write C1 among 128^2) vs v2: rerun both once
-    a0.W = Ws[0]; a1.W = Ws[0];
-    run_cold(v2<128, 128, 2, 4>, 128, 128, 2 * 256 * 128, a0, Ws, 1, 512);
-    run_cold(v3<128, 128, 2, 4, 4>, 128, 128, 4 * 256 * 128, a1, Ws, 1, 512);
     std::vector<uint16_t> h0((size_t)M * N), h1((size_t)M * N);
-    CK(hipMemcpy(h0.data(), C0, h0.size() * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(h1.data(), C1, h1.size() * 2, hipMemcpyDeviceToHost));
-    size_t bad = 0; for (size_t i = 0; i < h0.size(); ++i) bad += h0[i] != h1[i];
-    run_cold(v3<64, 256, 1, 4, 3>, 64, 256, 3 * 320 * 128, a1, Ws, 1, 256);
-    CK(hipMemcpy(h1.data(), C1, h1.size() * 2, hipMemcpyDeviceToHost));
-    size_t bad2 = 0; for (size_t i = 0; i < h0.size(); ++i) bad2 += h0[i] != h1[i];
-    printf("M=%5d N=%6d K=%5d cold(%d W) | 128^2: v2 %6.1f  v3/2 %6.1f  v3/3 %6.1f  v3/4 %6.1f | 64x256: v2 %6.1f  v3/3 %6.1f | 64x512/8w v3/2 %6.1f | mismatch %zu %zu\n",
-           M, N, K, nW, a_, b_, c_, d_, e_, f_, g_, bad, bad2);
+    auto check = [&]() {
+      CK(hipDeviceSynchronize());
+      CK(hipMemcpy(h1.data(), C1, h1.size() * 2, hipMemcpyDeviceToHost));
+      size_t bad = 0; for (size_t i = 0; i < h0.size(); ++i) bad += h0[i] != h1[i];
+      CK(hipMemset(C1, 0, (size_t)M * N * 2));
+      return bad;
+    };
+    const float r2 = run_cold(v3<64, 256, 1, 4, 2>, 64, 256, 2 * 320 * 128, a0, Ws, it, 256);
+    const float r3 = run_cold(v3<64, 256, 1, 4, 3>, 64, 256, 3 * 320 * 128, a0, Ws, it, 256);
+    run_cold(v3<64, 256, 1, 4, 3>, 64, 256, 3 * 320 * 128, a0, Ws, 1, 256);
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(h0.data(), C0, h0.size() * 2, hipMemcpyDeviceToHost));
+    printf("M=%5d N=%6d K=%5d cold(%d W) | v3 64x256: NS2 %6.1f NS3 %6.1f |", M, N, K, nW, r2, r3);
+    { const float t = run_cold(v6<64, 256, 8, 4>, 64, 256, 4 * 64 * 128, a1, Ws, it, 512); printf(" v6 64x256/8w NS4 %6.1f (bad %zu)", t, check()); }
+    { const float t = run_cold(v6<64, 256, 8, 6>, 64, 256, 6 * 64 * 128, a1, Ws, it, 512); printf(" NS6 %6.1f (bad %zu)", t, check()); }
+    { const float t = run_cold(v6<64, 256, 8, 8>, 64, 256, 8 * 64 * 128, a1, Ws, it, 512); printf(" NS8 %6.1f (bad %zu)", t, check()); }
+    { const float t = run_cold(v6<64, 256, 8, 4, true>, 64, 256, 4 * 64 * 128, a1, Ws, it, 512); printf(" | PACKED NS4 %6.1f", t); check(); }
+    { const float t = run_cold(v6<64, 256, 8, 8, true>, 64, 256, 8 * 64 * 128, a1, Ws, it, 512); printf(" NS8 %6.1f", t); check(); }
+    { const float t = run_cold(v6<320, 128, 8, 3, true>, 320, 128, 3 * 320 * 128, a1, Ws, it, 512); printf(" 320x128 NS3 %6.1f", t); check(); }
+    { const float t = run_cold(v6<160, 128, 4, 4, true>, 160, 128, 4 * 160 * 128, a1, Ws, it, 256); printf(" 160x128 NS4 %6.1f", t); check(); }
+    { const float t = run_cold(v6<64, 128, 4, 6>, 64, 128, 6 * 64 * 128, a1, Ws, it, 256); printf(" | 64x128/4w NS6 %6.1f (bad %zu)", t, check()); }
+    { const float t = run_cold(v6<160, 128, 4, 4>, 160, 128, 4 * 160 * 128, a1, Ws, it, 256); printf(" | 160x128/4w NS4 %6.1f (bad %zu)", t, check()); }
+    { const float t = run_cold(v6<320, 128, 8, 3>, 320, 128, 3 * 320 * 128, a1, Ws, it, 512); printf(" | 320x128/8w NS3 %6.1f (bad %zu)", t, check()); }
+    printf("\n");
     fflush(stdout);
     hipFree(A); hipFree(C0); hipFree(C1); for (auto w : Ws) hipFree(w);
   }
