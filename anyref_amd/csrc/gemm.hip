@@ -575,10 +575,13 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, int splits
 // Split-K reduction of one output ROW per workgroup with the RMSNorm that follows fused in: sums the slabs
 // in a fixed order, applies bias / activation / residual, writes C, then y = C * rsqrt(mean C^2 + eps) * gain
 // as T.  Saves a launch and a pass over x per prefill o_proj / down_proj (N <= 8192).
-template <typename T>
-__global__ __launch_bounds__(256) void splitk_reduce_norm_kernel(const float* __restrict__ slabs, int splits,
-                                                                 int64_t slab_stride, GemmArgs a) {
-  constexpr int MAXV = 8;  // float4 per thread: N <= 256 * 4 * 8
+// NT threads per row, SP slabs (0: run-time count).  With 1024 threads a 4096-wide row is one float4 column per
+// thread and the SP slab loads + the residual load of a thread are straight-line code, all in flight together; the
+// 256-thread / run-time-count form walked 4 columns x 4 slabs as ~16 dependent round trips (11.6 us per launch).
+template <typename T, int NT, int SP>
+__global__ __launch_bounds__(NT) void splitk_reduce_norm_kernel(const float* __restrict__ slabs, int splits,
+                                                                int64_t slab_stride, GemmArgs a) {
+  constexpr int MAXV = 8192 / (4 * NT);  // float4 per thread: N <= 8192
   const int m = blockIdx.x, tid = threadIdx.x, nv = a.N / 4;
   float* Cf = reinterpret_cast<float*>(a.C);
   T* Ct = reinterpret_cast<T*>(a.C);
@@ -586,12 +589,22 @@ __global__ __launch_bounds__(256) void splitk_reduce_norm_kernel(const float* __
   float ss = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
-    const int c = tid + i * 256;
+    const int c = tid + i * NT;
     if (c < nv) {
       const int n = c * 4;
       const int64_t e = (int64_t)m * a.N + n;
-      float4v acc = *reinterpret_cast<const float4v*>(slabs + e);
-      for (int z = 1; z < splits; ++z) acc += *reinterpret_cast<const float4v*>(slabs + z * slab_stride + e);
+      float4v acc;
+      if constexpr (SP > 0) {
+        float4v t[SP];
+#pragma unroll
+        for (int z = 0; z < SP; ++z) t[z] = *reinterpret_cast<const float4v*>(slabs + z * slab_stride + e);
+        acc = t[0];
+#pragma unroll
+        for (int z = 1; z < SP; ++z) acc += t[z];  // same order as the run-time loop: bit-identical
+      } else {
+        acc = *reinterpret_cast<const float4v*>(slabs + e);
+        for (int z = 1; z < splits; ++z) acc += *reinterpret_cast<const float4v*>(slabs + z * slab_stride + e);
+      }
       acc *= a.alpha;
       if (a.col_scale) acc *= *reinterpret_cast<const float4v*>(a.col_scale + n);
       if (a.bias) acc += *reinterpret_cast<const float4v*>(a.bias + n);
@@ -610,14 +623,17 @@ __global__ __launch_bounds__(256) void splitk_reduce_norm_kernel(const float* __
     }
   }
   ss = wave_sum(ss);
-  __shared__ float red[4];
+  __shared__ float red[NT / 64];
   if ((tid & 63) == 0) red[tid >> 6] = ss;
   __syncthreads();
-  const float scale = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)a.N + a.norm_eps);
+  float tot = 0.f;
+#pragma unroll
+  for (int w = 0; w < NT / 64; ++w) tot += red[w];
+  const float scale = rsqrtf(tot / (float)a.N + a.norm_eps);
   T* y = reinterpret_cast<T*>(a.norm_out) + (int64_t)m * a.norm_ld;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
-    const int c = tid + i * 256;
+    const int c = tid + i * NT;
     if (c < nv) {
       const int n = c * 4;
       const float4v g = *reinterpret_cast<const float4v*>(a.norm_gain + n);
@@ -716,7 +732,12 @@ void launch_gemm(const GemmArgs& a_in, hipStream_t s) {
       g.bias = nullptr; g.resid = nullptr; g.act = ACT_NONE; g.alpha = 1.f; g.col_scale = nullptr; g.swiglu_pairs = 0;
       launch_gemm<T>(g, s);
       if (a.norm_out && a.norm_gain && a.N <= 8192 && a.norm_ld % 4 == 0 && !a.swiglu_pairs) {
-        hipLaunchKernelGGL((splitk_reduce_norm_kernel<T>), dim3(a.M), dim3(256), 0, s, ws, splits, slab, a);
+        if (splits == 4 && a.N > 2048)
+          hipLaunchKernelGGL((splitk_reduce_norm_kernel<T, 1024, 4>), dim3(a.M), dim3(1024), 0, s, ws, splits, slab, a);
+        else if (a.N > 2048)
+          hipLaunchKernelGGL((splitk_reduce_norm_kernel<T, 1024, 0>), dim3(a.M), dim3(1024), 0, s, ws, splits, slab, a);
+        else
+          hipLaunchKernelGGL((splitk_reduce_norm_kernel<T, 256, 0>), dim3(a.M), dim3(256), 0, s, ws, splits, slab, a);
         if (a.norm_done) *a.norm_done = true;
         return;
       }
@@ -852,7 +873,8 @@ void launch_gemm(const GemmArgs& a_in, hipStream_t s) {
         // prefill gate/up (320 x 22016 x 4096): every workgroup owns a weight panel outright (all of M in one
         // tile, 230 panels on 256 CUs) instead of five 64-row workgroups sharing one: 7 % faster from cold weights
         go(I320(), std::integral_constant<int, 96>(), I4(), I2(), I2(), "gemm_bf16_320x96");
-      else if (!a.w_fp8 && knobs().m320 >= 0 && a.M > 192 && a.M <= 320 && a.batch > 1 && (int64_t)cdiv(a.N, 64) * a.batch <= cus)
+      else if (!a.w_fp8 && knobs().m320 >= 0 && a.M > 192 && a.M <= 320 && a.batch > 1 && (int64_t)cdiv(a.N, 64) * a.batch <= cus &&
+               (int64_t)cdiv(a.N, 64) * a.batch * 4 >= cus * 3)  // (CLIP fc2's 128 slabs stay on 128^2 tiles: 192 workgroups)
         // split-K slabs of prefill o_proj / down_proj: 64 column panels x 4 K slices = 256 workgroups, one round, all
         // of M per tile (o_proj 30.2 -> 26.9 us, down_proj 55.3 -> 49.1 us with the reduction; qkv on 320 x 48 /
         // 320 x 64 tiles measured 5 % slower than 64 x 256 and stays there)
