@@ -67,6 +67,7 @@ SYMBOLS = {
     "anyref_seg_tail": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _L, _P, _P]),
     "anyref_set_seg_range": (_I, [_P, _I, _I]),
     "anyref_set_overlap": (_I, [_P, _I]),
+    "anyref_set_early_tail": (_I, [_P, _I]),
     "anyref_set_graphs": (_I, [_P, _I]),
     "anyref_profile_enable": (_I, [_P, _I]),
     "anyref_profile_config": (_I, [_P, C.c_char_p, _I]),

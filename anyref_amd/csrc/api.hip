@@ -129,6 +129,7 @@ int anyref_seg_tail(anyref_handle* h, void* stream, const float* sam_images, con
 int anyref_set_seg_range(anyref_handle* h, int lo, int hi) { GUARD(h, h->m->set_seg_range(lo, hi)); }
 
 int anyref_set_overlap(anyref_handle* h, int on) { GUARD(h, h->m->set_overlap(on != 0)); }
+int anyref_set_early_tail(anyref_handle* h, int on) { GUARD(h, h->m->set_early_tail(on != 0)); }
 
 int anyref_set_graphs(anyref_handle* h, int on) { GUARD(h, h->m->set_graphs(on != 0)); }
 

@@ -65,8 +65,11 @@ class ModelBase {
   // two-stream overlap of the SAM encoder with the LLM decode (default on; measurement harness can
   // switch it off to time kernels without a co-running stream)
   void set_overlap(bool on) { overlap_ = on; }
+  // masks of generated [SEG]s decoded on the side stream while the greedy loop goes on (default on; batch 1)
+  void set_early_tail(bool on) { early_off_ = !on; }
   // hipGraph replay of the greedy decode step (default on)
   void set_graphs(bool on) { use_graphs_ = on; }
+  bool early_off_ = getenv("ANYREF_NO_EARLY_TAIL") != nullptr;
   Profiler prof;
   std::string err;
   int n_unknown = 0;

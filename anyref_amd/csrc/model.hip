@@ -288,6 +288,11 @@ class Model : public ModelBase {
                 const int32_t* orig_hw, int32_t* out_nseg, float* out_masks, int64_t out_masks_cap,
                 int64_t* mask_offsets, float* out_low, const float* attn_given = nullptr, int attn_n = 0);
   void join_sam(hipStream_t s);
+  // mask of a [SEG] the greedy loop has just emitted, on the side stream, while the loop goes on (generate, batch 1)
+  void early_seg(hipEvent_t hidden_ready, int hidden_row, const int32_t* resized_hw, const int32_t* orig_hw,
+                 float* out_masks, int64_t out_masks_cap, float* out_low);
+  int early_done_ = 0;       // [SEG]s of this call already decoded by early_seg (in order of appearance)
+  bool early_stop_ = false;  // a limit was hit: the tail decodes (or refuses) the rest
   // SAM image encoder on a second stream: it depends on nothing but the image, is MFMA-bound, and
   // overlaps the HBM-bound LLM decode (fork at the start of a call, join before the mask decoder).
   void fork_sam(hipStream_t s, const float* sam_images, int B);
@@ -1514,6 +1519,34 @@ struct SamJoinGuard {
 };
 }  // namespace
 
+// A generated [SEG] needs nothing that comes after it: its hidden row is final when the token is read, and the image
+// embedding is on the side stream anyway.  So its hand-off MLP, mask decoder and postprocess are queued on that stream
+// (behind the encoder) the moment the host sees the token, and run under the remaining decode steps instead of after
+// the loop (the reference always emits at least the EOS after a [SEG]; ~1 ms per image at batch 1).
+template <typename T>
+void Model<T>::early_seg(hipEvent_t hidden_ready, int hidden_row, const int32_t* resized_hw, const int32_t* orig_hw,
+                         float* out_masks, int64_t out_masks_cap, float* out_low) {
+  const anyref_config& c = cfg;
+  const int H = c.llm_dim, slot = early_done_, L = 4 * sam_g_;
+  const int64_t hw = (int64_t)orig_hw[0] * orig_hw[1];
+  if (slot >= c.max_seg || (slot + 1) * hw > out_masks_cap) {  // run_tail refuses the call with the proper message
+    early_stop_ = true;
+    return;
+  }
+  HIP_TRY(hipStreamWaitEvent(s2_, hidden_ready, 0));
+  HIP_TRY(hipMemcpyAsync(seg_h_ + (size_t)slot * H, hidden_all_ + (size_t)hidden_row * H, (size_t)H * 4,
+                         hipMemcpyDeviceToDevice, s2_));
+  gemmf(s2_, seg_h_ + (size_t)slot * H, H, fc1_, seg_t_ + (size_t)slot * H, H, 1, ACT_RELU);
+  gemmf(s2_, seg_t_ + (size_t)slot * H, H, fc2_, pred_emb_ + (size_t)slot * c.out_dim, c.out_dim, 1, ACT_NONE);
+  mask_decoder(s2_, sam_emb_, pred_emb_ + (size_t)slot * c.out_dim, 1, nullptr, nullptr);
+  launch_postprocess(m_masks_, (int64_t)c.num_mask_tokens * L * L, 1, L, L, c.sam_img, resized_hw[0], resized_hw[1],
+                     orig_hw[0], orig_hw[1], out_masks + slot * hw, s2_);
+  if (out_low)
+    HIP_TRY(hipMemcpyAsync(out_low + (size_t)slot * L * L, m_masks_, (size_t)L * L * 4, hipMemcpyDeviceToDevice, s2_));
+  HIP_TRY(hipEventRecord(ev_sam_, s2_));  // the join now waits for this mask too
+  ++early_done_;
+}
+
 template <typename T>
 void Model<T>::run_tail(hipStream_t s, const float* sam_images, int B, const std::vector<int>& seg_b,
                         const std::vector<int>& seg_pos, const std::vector<int>& reph_s, const int32_t* resized_hw,
@@ -1526,6 +1559,8 @@ void Model<T>::run_tail(hipStream_t s, const float* sam_images, int B, const std
   // join BEFORE anything below can throw: a refused call must not leave the encoder running on the side stream
   // over the caller's images, nor a stale "forked" flag for the next call
   const bool sam_ready = sam_forked_;
+  const int done = early_done_;  // generate, batch 1: rows [0, done) were decoded by early_seg, masks and all
+  early_done_ = 0;
   join_sam(s);
   for (int b = 0; b < B; ++b) out_nseg[b] = 0;
   for (int i = 0; i < nseg; ++i) out_nseg[seg_b[i]]++;
@@ -1537,7 +1572,8 @@ void Model<T>::run_tail(hipStream_t s, const float* sam_images, int B, const std
     off += (int64_t)out_nseg[b] * orig_hw[2 * b] * orig_hw[2 * b + 1];
   }
   if (off > out_masks_cap) throw std::runtime_error("out_masks capacity too small");
-  if (nseg == 0) return;
+  if (done > nseg) throw std::runtime_error("internal: more early [SEG] masks than [SEG] tokens");
+  if (nseg == done) return;
   for (int i = 0; i < nseg; ++i) {
     stage_seg_[i] = seg_b[i];
     stage_seg_[nseg + i] = seg_pos[i];
@@ -1577,15 +1613,20 @@ void Model<T>::run_tail(hipStream_t s, const float* sam_images, int B, const std
   for (int b = 0; b < B; ++b) {
     const int n = out_nseg[b];
     if (n == 0) continue;
+    const int j0 = b == 0 ? done : 0;  // early masks (batch 1) are already in place
+    const int64_t hw = (int64_t)orig_hw[2 * b] * orig_hw[2 * b + 1];
     // seg rows of image b are contiguous because the host emits them image by image
-    mask_decoder(s, sam_emb_ + (size_t)b * NK * C, pred_emb_ + (size_t)row * c.out_dim, n, nullptr, nullptr);
-    launch_postprocess(m_masks_, (int64_t)c.num_mask_tokens * L * L, n, L, L, c.sam_img, resized_hw[2 * b],
-                       resized_hw[2 * b + 1], orig_hw[2 * b], orig_hw[2 * b + 1], out_masks + mask_offsets[b], s);
-    if (out_low)
-      for (int j = 0; j < n; ++j)
-        HIP_TRY(hipMemcpyAsync(out_low + ((size_t)b * c.max_seg + j) * L * L,
-                               m_masks_ + (size_t)j * c.num_mask_tokens * L * L, (size_t)L * L * 4,
-                               hipMemcpyDeviceToDevice, s));
+    if (n > j0) {
+      mask_decoder(s, sam_emb_ + (size_t)b * NK * C, pred_emb_ + (size_t)(row + j0) * c.out_dim, n - j0, nullptr, nullptr);
+      launch_postprocess(m_masks_, (int64_t)c.num_mask_tokens * L * L, n - j0, L, L, c.sam_img, resized_hw[2 * b],
+                         resized_hw[2 * b + 1], orig_hw[2 * b], orig_hw[2 * b + 1], out_masks + mask_offsets[b] + j0 * hw,
+                         s);
+      if (out_low)
+        for (int j = j0; j < n; ++j)
+          HIP_TRY(hipMemcpyAsync(out_low + ((size_t)b * c.max_seg + j) * L * L,
+                                 m_masks_ + (size_t)(j - j0) * c.num_mask_tokens * L * L, (size_t)L * L * 4,
+                                 hipMemcpyDeviceToDevice, s));
+    }
     row += n;
   }
 }
@@ -1643,6 +1684,13 @@ void Model<T>::generate(hipStream_t s, const float* clip_images, const float* sa
   // value: its copy and an event are queued, THEN the next step, and the host waits for the event while the device
   // already runs that step -- no host round trip between steps.
   const bool ahead = eos_token_id < 0;
+  // early [SEG] masks: batch 1, encoder on the side stream, no rephrasing (that reads attention over the whole answer),
+  // no [SEG] inside the prompt (the tail's order is by position)
+  early_done_ = 0;
+  early_stop_ = false;
+  bool early = !early_off_ && sam_forked_ && B == 1 && c.rephrase_weight <= 0.f;
+  for (int i = 1; early && i < lens[0]; ++i)
+    if (input_ids[i] >= c.seg_lo && input_ids[i] <= c.seg_hi) early = false;
   for (int step = 0; step < max_new_tokens; ++step) {
     int64_t* tok = next_host_ + (size_t)(step & 1) * c.max_batch;
     const bool last = step == max_new_tokens - 1;
@@ -1655,6 +1703,9 @@ void Model<T>::generate(hipStream_t s, const float* clip_images, const float* sa
       if (!fin[b]) {
         gen[b].push_back(tok[b]);
         if (eos_token_id >= 0 && tok[b] == eos_token_id) fin[b] = 1;
+        // token `step` was predicted by hidden row slen + step - 1, final since ev_tok_ of this step
+        if (early && !early_stop_ && tok[b] >= c.seg_lo && tok[b] <= c.seg_hi)
+          early_seg(ev_tok_[step & 1], slen[0] + step - 1, resized_hw, orig_hw, out_masks, out_masks_cap, out_low);
       }
       all = all && fin[b];
     }

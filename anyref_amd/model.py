@@ -66,7 +66,7 @@ def _c_config(cfg: AnyRefConfig, mode: int, max_batch: int, max_seg: int) -> _li
 
 _NEEDS_HANDLE = frozenset({
     "generate", "model_forward_new", "forward", "__call__", "encode_images", "sam_encode", "mask_decode", "llm_forward",
-    "seg_tail", "postprocess", "audio_encode", "device_bytes", "set_overlap", "set_graphs", "profile_enable", "profile_read"})
+    "seg_tail", "postprocess", "audio_encode", "device_bytes", "set_overlap", "set_early_tail", "set_graphs", "profile_enable", "profile_read"})
 
 
 class AnyRefForCausalLM:
@@ -333,6 +333,10 @@ class AnyRefForCausalLM:
     def set_overlap(self, on: bool):
         """SAM encoder on a second stream under the LLM decode (default) or everything on one stream."""
         self._check(self.lib.anyref_set_overlap(self.h, int(on)), "set_overlap")
+
+    def set_early_tail(self, on: bool):
+        """Masks of generated [SEG]s decoded on the side stream while the greedy loop goes on (default; batch 1)."""
+        self._check(self.lib.anyref_set_early_tail(self.h, int(on)), "set_early_tail")
 
     def set_graphs(self, on: bool):
         """hipGraph replay of the greedy decode step (default) or eager launches."""

@@ -193,6 +193,12 @@ int anyref_set_seg_range(anyref_handle* h, int lo, int hi);
  * call on the caller's stream (used by bench.py to time kernels without a co-running stream). */
 int anyref_set_overlap(anyref_handle* h, int on);
 
+/* Early [SEG] masks (default 1; effective with overlap on, batch 1, rephrase_weight 0, no [SEG] in the prompt):
+ * anyref_generate queues the hand-off MLP, mask decoder and postprocess of a generated [SEG] on the side stream the
+ * moment the token is read, under the remaining decode steps (the reference runs them after generate() returns,
+ * anyref.py:718-822; same arithmetic per prompt, one prompt per mask-decoder call).  0: all masks after the loop. */
+int anyref_set_early_tail(anyref_handle* h, int on);
+
 /* hipGraph replay of the greedy decode step (default 1): one step is ~170 launches with fixed
  * arguments (position / next token live on the device), captured once per batch size.  0 launches
  * them eagerly; the per-kernel profiler below always runs eagerly. */

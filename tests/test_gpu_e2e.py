@@ -205,6 +205,7 @@ def test_decode_launch_modes_bit_identical(mode, B):
     m = AnyRefForCausalLM.from_state_dict(cfg, {k: v.cuda() for k, v in sd.items()}, mode=mode, max_batch=B, max_seg=4)
     m.config.eos_token_id = None
     m.set_graphs(False)
+    m.set_early_tail(False)   # its one-prompt-per-call mask decoding is compared in test_early_seg_masks
     out0, _, _ = m.generate(clip, ids_p, sam, sizes, H, W, max_new_tokens=5)
     m.set_seg_token_idx(int(out0[0, ids_p.shape[1] + 2]))       # a [SEG] for row 0 at least
     ref = None
@@ -222,6 +223,66 @@ def test_decode_launch_modes_bit_identical(mode, B):
             assert torch.equal(cur[1], ref[1]), f"hidden states differ ({tag})"
             for a, b in zip(cur[2], ref[2]):
                 assert (a is None) == (b is None) and (a is None or torch.equal(a, b)), f"masks differ ({tag})"
+
+
+@pytest.mark.parametrize("mode", ["parity", "perf"])
+def test_early_seg_masks(mode):
+    """generate() at batch 1 decodes the mask of a generated [SEG] on the side stream as soon as the token is read
+    (anyref_set_early_tail).  Same ids and hidden states bit for bit; the masks agree with the after-the-loop path to
+    f32 rounding (one prompt per mask-decoder call instead of all prompts of the image in one), for one [SEG], for
+    several, with and without an EOS id, and when the [SEG] budget is exceeded both paths refuse the call."""
+    from anyref_amd.model import AnyRefForCausalLM
+    cfg = config_tiny()
+    sd = synth_state_dict(cfg, seed=5, init="fan_in")        # O(1) logits: a varied greedy answer
+    clip, sam, ids = make_inputs(cfg, 1, seed=6, L=16)
+    ids_p, _ = pad(ids)
+    sizes, H, W = [(200, 224)], [150], [170]
+    m = AnyRefForCausalLM.from_state_dict(cfg, {k: v.cuda() for k, v in sd.items()}, mode=mode, max_batch=1, max_seg=4)
+    m.config.eos_token_id = None
+    m.set_early_tail(False)
+    out0, _, _ = m.generate(clip, ids_p, sam, sizes, H, W, max_new_tokens=12)
+    gen = out0[0, ids_p.shape[1]:].tolist()
+    prompt = set(ids_p[0].tolist())
+    counts = {t: gen.count(t) for t in gen if t not in prompt}
+    assert counts, gen
+    cases = [(f"[SEG] x {n}", t, None) for t, n in sorted(counts.items(), key=lambda kv: kv[1])[:3] if n <= 4]
+    last = gen[-1]
+    if last in counts and counts[last] <= 4:
+        cases.append(("[SEG] is the last token", last, None))
+    for t in counts:                                        # an EOS right behind the first [SEG]
+        k = gen.index(t)
+        if counts[t] <= 4 and k + 1 < len(gen) and gen[k + 1] != t:
+            cases.append(("EOS right after", t, gen[k + 1]))
+            break
+    assert cases, gen
+    for tag, seg, eos in cases:
+        m.set_seg_token_idx(int(seg))
+        m.config.eos_token_id = eos
+        res = []
+        for early in (False, True):
+            m.set_early_tail(early)
+            (o_ids, masks, _), ex = m.generate(clip, ids_p, sam, sizes, H, W, max_new_tokens=12, _return_extras=True)
+            res.append((o_ids.cpu(), ex["hidden"].cpu(), masks[0].cpu(), ex["low_res"].cpu()))
+        a, b = res
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), tag
+        assert a[2].shape == b[2].shape and a[2].shape[0] >= 1 and a[2].shape[1:] == (150, 170), (tag, a[2].shape)
+        scale = max(a[2].abs().max().item(), 1.0)
+        assert (a[2] - b[2]).abs().max().item() <= 2e-5 * scale, (tag, (a[2] - b[2]).abs().max().item(), scale)
+        assert (a[3] - b[3]).abs().max().item() <= 2e-5 * scale, tag
+    # more [SEG]s than max_seg: refused on both paths, and the handle stays usable
+    worst = max(counts, key=counts.get)
+    if counts[worst] > 4:
+        m.config.eos_token_id = None
+        m.set_seg_token_idx(int(worst))
+        for early in (False, True):
+            m.set_early_tail(early)
+            with pytest.raises(RuntimeError, match="max_seg"):
+                m.generate(clip, ids_p, sam, sizes, H, W, max_new_tokens=12)
+    m.config.eos_token_id = None
+    m.set_seg_token_idx(int(cases[0][1]))
+    m.set_early_tail(True)
+    _, masks, _ = m.generate(clip, ids_p, sam, sizes, H, W, max_new_tokens=12)
+    assert masks[0].shape[0] == counts[cases[0][1]]
 
 
 def test_limits_and_error_paths():
