@@ -578,10 +578,11 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, int splits
 // NT threads per row, SP slabs (0: run-time count).  With 1024 threads a 4096-wide row is one float4 column per
 // thread and the SP slab loads + the residual load of a thread are straight-line code, all in flight together; the
 // 256-thread / run-time-count form walked 4 columns x 4 slabs as ~16 dependent round trips (11.6 us per launch).
-template <typename T, int NT, int SP>
+// MAXV: float4 columns per thread, N <= 4 * NT * MAXV (instantiated tight: the unrolled column loop is code the
+// instruction fetch pays for whether or not a column is live)
+template <typename T, int NT, int SP, int MAXV>
 __global__ __launch_bounds__(NT) void splitk_reduce_norm_kernel(const float* __restrict__ slabs, int splits,
                                                                 int64_t slab_stride, GemmArgs a) {
-  constexpr int MAXV = 8192 / (4 * NT);  // float4 per thread: N <= 8192
   const int m = blockIdx.x, tid = threadIdx.x, nv = a.N / 4;
   float* Cf = reinterpret_cast<float*>(a.C);
   T* Ct = reinterpret_cast<T*>(a.C);
@@ -622,8 +623,30 @@ __global__ __launch_bounds__(NT) void splitk_reduce_norm_kernel(const float* __r
       v[i] = float4v{0.f, 0.f, 0.f, 0.f};
     }
   }
-  ss = wave_sum(ss);
   __shared__ float red[NT / 64];
+  float mean = 0.f;
+  if (a.norm_bias) {  // LayerNorm (CLIP / audio blocks): two passes over the registers, as norm_kernel does
+    float s1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) s1 += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+    s1 = wave_sum(s1);
+    if ((tid & 63) == 0) red[tid >> 6] = s1;
+    __syncthreads();
+    float tot1 = 0.f;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) tot1 += red[w];
+    mean = tot1 / (float)a.N;
+    __syncthreads();
+    ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      if (tid + i * NT < nv) {
+        v[i] -= mean;
+        ss += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
+      }
+    }
+  }
+  ss = wave_sum(ss);
   if ((tid & 63) == 0) red[tid >> 6] = ss;
   __syncthreads();
   float tot = 0.f;
@@ -637,10 +660,12 @@ __global__ __launch_bounds__(NT) void splitk_reduce_norm_kernel(const float* __r
     if (c < nv) {
       const int n = c * 4;
       const float4v g = *reinterpret_cast<const float4v*>(a.norm_gain + n);
-      y[n] = from_f32<T>(v[i][0] * scale * g[0]);
-      y[n + 1] = from_f32<T>(v[i][1] * scale * g[1]);
-      y[n + 2] = from_f32<T>(v[i][2] * scale * g[2]);
-      y[n + 3] = from_f32<T>(v[i][3] * scale * g[3]);
+      float4v o = v[i] * scale * g;
+      if (a.norm_bias) o += *reinterpret_cast<const float4v*>(a.norm_bias + n);
+      y[n] = from_f32<T>(o[0]);
+      y[n + 1] = from_f32<T>(o[1]);
+      y[n + 2] = from_f32<T>(o[2]);
+      y[n + 3] = from_f32<T>(o[3]);
     }
   }
 }
@@ -714,7 +739,9 @@ void launch_gemm(const GemmArgs& a_in, hipStream_t s) {
     throw std::runtime_error("gemm: the SwiGLU epilogue takes interleaved gate/up rows, N % 4 == 0, and nothing else");
   constexpr int VEC = Mma<T>::VEC;
   // ---- split-K decision: few 64x64 tiles, deep K, plain row-major output ----
-  if (!knobs().no_splitk && sizeof(T) == 2 && a.batch == 1 && !a.row_map && a.M <= 512 && a.K >= 2048 && a.N % 4 == 0 && a.ldc % 4 == 0 &&
+  // (K >= 1024 when a norm rides on the reduction: CLIP out_proj, 24 tiles of 16 K steps + a LayerNorm launch otherwise)
+  if (!knobs().no_splitk && sizeof(T) == 2 && a.batch == 1 && !a.row_map && a.M <= 512 &&
+      (a.K >= 2048 || (a.K >= 1024 && a.norm_out && a.norm_bias)) && a.N % 4 == 0 && a.ldc % 4 == 0 &&
       (!a.resid || a.ldr % 4 == 0)) {
     // 128 x 128 workgroups (two per CU): split until there are ~256 of them, slices of >= 512, multiples of 64
     const int64_t tiles = (int64_t)cdiv(a.M, 128) * cdiv(a.N, 128);
@@ -732,12 +759,28 @@ void launch_gemm(const GemmArgs& a_in, hipStream_t s) {
       g.bias = nullptr; g.resid = nullptr; g.act = ACT_NONE; g.alpha = 1.f; g.col_scale = nullptr; g.swiglu_pairs = 0;
       launch_gemm<T>(g, s);
       if (a.norm_out && a.norm_gain && a.N <= 8192 && a.norm_ld % 4 == 0 && !a.swiglu_pairs) {
-        if (splits == 4 && a.N > 2048)
-          hipLaunchKernelGGL((splitk_reduce_norm_kernel<T, 1024, 4>), dim3(a.M), dim3(1024), 0, s, ws, splits, slab, a);
-        else if (a.N > 2048)
-          hipLaunchKernelGGL((splitk_reduce_norm_kernel<T, 1024, 0>), dim3(a.M), dim3(1024), 0, s, ws, splits, slab, a);
-        else
-          hipLaunchKernelGGL((splitk_reduce_norm_kernel<T, 256, 0>), dim3(a.M), dim3(256), 0, s, ws, splits, slab, a);
+        auto rn = [&](auto nt_t, auto sp_t, auto mv_t) {
+          constexpr int NT = decltype(nt_t)::value, SP = decltype(sp_t)::value, MV = decltype(mv_t)::value;
+          hipLaunchKernelGGL((splitk_reduce_norm_kernel<T, NT, SP, MV>), dim3(a.M), dim3(NT), 0, s, ws, splits, slab, a);
+        };
+        using C0 = std::integral_constant<int, 0>;
+        using C1 = std::integral_constant<int, 1>;
+        using C2 = std::integral_constant<int, 2>;
+        using C4 = std::integral_constant<int, 4>;
+        using C8 = std::integral_constant<int, 8>;
+        using C256 = std::integral_constant<int, 256>;
+        using C1024 = std::integral_constant<int, 1024>;
+        if (a.N <= 1024) {  // CLIP (N = 1024): one column per thread of a 256-thread row
+          if (splits == 8) rn(C256(), C8(), C1());
+          else if (splits == 2) rn(C256(), C2(), C1());
+          else rn(C256(), C0(), C1());
+        } else if (a.N <= 4096) {  // LLM 7B (N = 4096)
+          if (splits == 4) rn(C1024(), C4(), C1());
+          else rn(C1024(), C0(), C1());
+        } else {
+          if (splits == 4) rn(C1024(), C4(), C2());
+          else rn(C1024(), C0(), C2());
+        }
         if (a.norm_done) *a.norm_done = true;
         return;
       }

@@ -92,6 +92,7 @@ struct GemmArgs {
   void* norm_out = nullptr;  // T [M, N], row stride norm_ld
   int norm_ld = 0;
   float norm_eps = 0.f;
+  const float* norm_bias = nullptr;  // set: LayerNorm (mean removed, + bias) instead of RMSNorm
   bool* norm_done = nullptr;
   // optional batching over blockIdx.z (element strides)
   int batch = 1;

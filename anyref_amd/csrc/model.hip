@@ -190,12 +190,18 @@ class Model : public ModelBase {
   // takes its split-K path; returns whether that happened (else the caller runs the norm itself)
   bool gemm(hipStream_t s, const T* A, int lda, const Lin<T>& l, void* C, int ldc, int M, int act, bool c_f32,
             const float* resid = nullptr, int ldr = 0, const int* row_map = nullptr, const Affine* nrm = nullptr,
-            T* nrm_out = nullptr, bool swiglu = false) {
+            T* nrm_out = nullptr, bool swiglu = false, float ln_eps = -1.f) {
+    // nrm / nrm_out: the norm that follows (RMSNorm with the LLM's eps; LayerNorm with ln_eps when ln_eps >= 0) is
+    // applied by the split-K reduction if the GEMM takes that path -- the return value says whether it did
     GemmArgs a;
     bool fused = false;
     a.swiglu_pairs = swiglu ? 1 : 0;
     if (nrm && nrm_out) {
       a.norm_gain = nrm->g; a.norm_out = nrm_out; a.norm_ld = l.n; a.norm_eps = cfg.llm_rms_eps; a.norm_done = &fused;
+      if (ln_eps >= 0.f) {
+        a.norm_bias = nrm->b;
+        a.norm_eps = ln_eps;
+      }
     }
     a.A = A; a.lda = lda; a.W = l.w; a.ldw = l.stride(); a.bias = l.b; a.C = C; a.ldc = ldc; a.M = M; a.N = l.n;
     a.K = l.k; a.act = act; a.c_f32 = c_f32 ? 1 : 0; a.resid = resid; a.ldr = ldr; a.row_map = row_map;
@@ -1002,8 +1008,10 @@ void Model<T>::clip_tower(hipStream_t s, const float* images, int B) {
   gemm(s, c_col_, clip_kp_, clip_patch_, c_patch_, Dc, B * n, ACT_NONE, true);
   launch_clip_assemble(c_patch_, clip_cls_, clip_pos_, c_x_, B, n, Dc, s);
   norm(s, c_x_, Dc, clip_pre_, c_x_, Dc, R, Dc, c.clip_eps, true);
-  for (auto& L : clip_layers_) {
-    norm(s, c_x_, Dc, L.ln1, c_h_, Dc, R, Dc, c.clip_eps, false);
+  bool h_ready = false;  // ln1 already applied by the previous layer's fc2 reduction
+  for (size_t li = 0; li < clip_layers_.size(); ++li) {
+    auto& L = clip_layers_[li];
+    if (!h_ready) norm(s, c_x_, Dc, L.ln1, c_h_, Dc, R, Dc, c.clip_eps, false);
     gemm(s, c_h_, Dc, L.qkv, c_qkv_, 3 * Dc, R, ACT_NONE, false);
     AttnArgs a;
     a.Q = c_qkv_; a.K = c_qkv_ + Dc; a.V = c_qkv_ + 2 * Dc; a.O = c_att_;
@@ -1014,10 +1022,13 @@ void Model<T>::clip_tower(hipStream_t s, const float* images, int B) {
     a.B = B; a.H = c.clip_heads; a.Sq = S; a.Sk = S; a.hd = hd;
     a.scale = 1.f / sqrtf((float)hd);
     launch_attention<T>(a, s);
-    gemm(s, c_att_, Dc, L.out, c_x_, Dc, R, ACT_NONE, true, c_x_, Dc);
-    norm(s, c_x_, Dc, L.ln2, c_h_, Dc, R, Dc, c.clip_eps, false);
+    // the two LayerNorms of a block ride on the split-K reductions of the GEMMs in front of them (perf mode)
+    if (!gemm(s, c_att_, Dc, L.out, c_x_, Dc, R, ACT_NONE, true, c_x_, Dc, nullptr, &L.ln2, c_h_, false, c.clip_eps))
+      norm(s, c_x_, Dc, L.ln2, c_h_, Dc, R, Dc, c.clip_eps, false);
     gemm(s, c_h_, Dc, L.fc1, c_mlp_, c.clip_mlp, R, ACT_QUICK_GELU, false);
-    gemm(s, c_mlp_, c.clip_mlp, L.fc2, c_x_, Dc, R, ACT_NONE, true, c_x_, Dc);
+    const Affine* next = li + 1 < clip_layers_.size() ? &clip_layers_[li + 1].ln1 : nullptr;
+    h_ready = gemm(s, c_mlp_, c.clip_mlp, L.fc2, c_x_, Dc, R, ACT_NONE, true, c_x_, Dc, nullptr, next, c_h_, false,
+                   c.clip_eps);
   }
   for (int b = 0; b < B; ++b)  // drop CLS ("patch" feature select)
     launch_convert<T>(c_x_ + ((size_t)b * S + 1) * Dc, Dc, c_feat_ + (size_t)b * n * Dc, Dc, n, Dc, s);

@@ -119,3 +119,32 @@ def test_sam_h_shaped_encoder_vs_oracle(mode):
     e1 = close(emb, emb_ref, TOL[mode], "SAM-H-shaped image encoder vs oracle")
     e2 = close(emb[:, ::4, ::2, ::2], fx["emb"], TOL[mode], "SAM-H-shaped image encoder vs reference golden")
     print(f"[{mode}] SAM-H-width encoder max-abs-err vs oracle {e1:.3e}, vs reference {e2:.3e} (range {float(fx['absmax']):.2f})")
+
+
+@pytest.mark.parametrize("mode", ["parity", "perf"])
+def test_clip_l_shaped_tower_vs_oracle(mode):
+    """The CLIP tower at ViT-L/14's real shapes (257 tokens, width 1024, 16 heads of 64, MLP 4096, quick-GELU) cut to
+    4 layers (3 run: `hidden_states[-2]`), one image: the shapes at which the perf build takes its split-K paths --
+    out_proj (K = 1024) and fc2 (K = 4096) reduce f32 slabs and apply the LayerNorm that follows in the same kernel
+    (gemm.hip `splitk_reduce_norm_kernel`, LayerNorm form) -- against the fp32 restatement of
+    CLIPVisionModel (anyref.py:341-354 call site; oracle/anyref_oracle.py `clip_patch_tokens`)."""
+    from anyref_amd.config import AnyRefConfig, ClipConfig, LlmConfig, SamConfig
+    cfg = AnyRefConfig(
+        clip=ClipConfig(image_size=224, patch=14, dim=1024, heads=16, layers=4, mlp=4096),
+        llm=LlmConfig(vocab=500, dim=128, heads=4, layers=1, mlp=344, max_seq=512),
+        sam=SamConfig(img_size=224, patch=16, dim=64, depth=1, heads=1, window=14, global_idx=(0,)))
+    sd = synth_state_dict(cfg, seed=21, init="fan_in")        # O(1) activations through the residual stream
+    images = torch.randn(1, 3, 224, 224, generator=torch.Generator().manual_seed(22))
+    with torch.no_grad():
+        ref = O.clip_patch_tokens(sd, cfg, images)
+    m = build(cfg, sd, mode, max_batch=2, max_seg=2)
+    _, clip = m.encode_images(images, return_clip=True)
+    assert clip.shape == ref.shape == (1, 256, 1024)
+    e1 = close(clip, ref, TOL[mode], "CLIP-L-shaped tower, one image (split-K + fused LayerNorm in perf mode)")
+    # two images: 514 rows, past the split-K rule (M <= 512) -- the plain GEMM + LayerNorm launches
+    images2 = torch.cat([images, torch.randn(1, 3, 224, 224, generator=torch.Generator().manual_seed(23))])
+    with torch.no_grad():
+        ref2 = O.clip_patch_tokens(sd, cfg, images2)
+    _, clip2 = m.encode_images(images2, return_clip=True)
+    e2 = close(clip2, ref2, TOL[mode], "CLIP-L-shaped tower, two images")
+    print(f"[{mode}] CLIP-L-width tower max-abs-err vs oracle: {e1:.3e} (1 image), {e2:.3e} (2 images); range {ref.abs().max().item():.2f}")
