@@ -4,6 +4,7 @@
     python tools/trace_summary.py <trace dir> <iterations> [rows]           per (kernel, grid) table
     python tools/trace_summary.py <trace dir> <iterations> --overlap KEY    co-running analysis for kernels whose
                                                                             name contains KEY (e.g. gemv_kernel)
+    python tools/trace_summary.py <trace dir> <iterations> --gaps           device idle time inside the last generate call
 
 The overlap analysis answers the measurement question of DESIGN.md §6: does the profiler see the SAM encoder (second
 stream) running BESIDE the decode GEMVs, and what does a co-running launch cost?  For every launch of KEY it
@@ -65,6 +66,36 @@ def main():
             aa = sum(a) / len(a) if a else float("nan")
             cc = sum(c) / len(c) if c else float("nan")
             print(f"{k:72s} {len(a) / n:8.1f} {aa:8.2f} {len(c) / n:9.1f} {cc:8.2f} {cc / aa if a and c else float('nan'):6.2f}")
+        return
+    if "--gaps" in sys.argv:
+        # idle time between consecutive kernels of the LAST generate call in the trace (all queues merged): where the
+        # device waits for the host or for a dependent launch
+        rows.sort(key=lambda r: r["s"])
+        # the last iteration starts at the last clip_assemble (CLIP stem) launch
+        starts = [i for i, r in enumerate(rows) if "clip_assemble" in r["name"]]
+        it = rows[starts[-1]:]
+        busy_end, gaps, busy = it[0]["s"], [], 0
+        for a in it:
+            if a["s"] > busy_end:
+                gaps.append((a["s"] - busy_end, prev["name"][:50], a["name"][:50], (a["s"] - it[0]["s"]) / 1e6))
+            busy_end = max(busy_end, a["e"])
+            prev = a
+        span = (busy_end - it[0]["s"]) / 1e6
+        idle = sum(g[0] for g in gaps) / 1e6
+        print(f"last iteration: span {span:.3f} ms, device idle {idle:.3f} ms in {len(gaps)} gaps, {len(it)} launches")
+        hist = collections.Counter(min(int(g[0] / 1e3), 20) for g in gaps)
+        print("gap histogram (us: count):", dict(sorted(hist.items())))
+        by_pair = collections.defaultdict(lambda: [0, 0.0])
+        for g in gaps:
+            k = (g[1].split("<")[0].split("(")[0], g[2].split("<")[0].split("(")[0])
+            by_pair[k][0] += 1
+            by_pair[k][1] += g[0] / 1e3
+        print("idle by (previous kernel -> next kernel), us:")
+        for k, (c, t) in sorted(by_pair.items(), key=lambda kv: -kv[1][1])[:25]:
+            print(f"  {t:9.1f} us in {c:5d} gaps  {k[0]:36s} -> {k[1]}")
+        print("largest gaps:")
+        for g in sorted(gaps, reverse=True)[:12]:
+            print(f"  {g[0] / 1e3:8.1f} us at t={g[3]:7.3f} ms  {g[1]} -> {g[2]}")
         return
     top = int(sys.argv[3]) if len(sys.argv) > 3 else 60
     agg = collections.defaultdict(list)
