@@ -284,7 +284,27 @@ __global__ __launch_bounds__(NWV * 64) void attn_kernel(AttnArgs a) {
     kt_begin = split * chunk;
     kv_end = kv_end < kt_begin + chunk ? kv_end : kt_begin + chunk;
   }
-  if constexpr (NRES > 0) {
+  if constexpr (NRES > 0 && HD == 64) {
+    // short rows (CLIP): every resident tile requested before the first LDS store -- one round trip, not NRES
+    uint4v kall[NRES][KPT], vall[NRES][VPT];
+#pragma unroll
+    for (int t = 0; t < NRES; ++t) {
+      gload_tile(t * BKV);  // (tiles past kv_end load zeros)
+#pragma unroll
+      for (int i = 0; i < KPT; ++i) kall[t][i] = kreg[i];
+#pragma unroll
+      for (int i = 0; i < VPT; ++i) vall[t][i] = vreg[i];
+    }
+#pragma unroll
+    for (int t = 0; t < NRES; ++t) {
+#pragma unroll
+      for (int i = 0; i < KPT; ++i) kreg[i] = kall[t][i];
+#pragma unroll
+      for (int i = 0; i < VPT; ++i) vreg[i] = vall[t][i];
+      sstore_tile(t);
+    }
+    __syncthreads();
+  } else if constexpr (NRES > 0) {
 #pragma unroll
     for (int t = 0; t < NRES; ++t)
       if (t * BKV < kv_end) {
@@ -579,8 +599,8 @@ static void attn_launch_cfg(const AttnArgs& a_in, hipStream_t s) {
   constexpr int HDK = (HD + KS - 1) / KS * KS, LDK = HDK + VEC;
   constexpr int LDV = sizeof(T) == 2 ? ((HD * 2 + 255) / 256 * 256 + 32) / 2 : HD + VEC;
   size_t lds = sizeof(T) * (BKV * LDK + BKV * LDV) * (NRES > 0 ? NRES : 1);
-  if (NRES > 0 && (a.Sk > NRES * BKV || a.Sq > BQ || a.kv_len || a.causal))
-    throw std::runtime_error("attention: resident-key form needs Sk <= NRES * BKV and one query block");
+  if (NRES > 0 && (a.Sk > NRES * BKV || (a.Sq > BQ && a.rel_tab_h) || a.kv_len || a.causal))
+    throw std::runtime_error("attention: resident-key form needs Sk <= NRES * BKV (and one query block with rel-pos tables)");
   if (a.rel_h || a.rel_p || a.rel_tab_h) lds += sizeof(float) * BQ * (a.kh + a.kw);
   if (a.rel_tab_h) {
     if (NRES == 0 || sizeof(T) != 2 || 2 * a.kh - 1 > 32 || 2 * a.kw - 1 > 32 || a.rel_tab_ld % VEC ||
@@ -641,6 +661,16 @@ static void attn_launch(const AttnArgs& a, hipStream_t s) {
     // 6 waves 435 us, 4 waves (the default below) 337 us
     if (a.Sq >= 1024 && !a.causal) {
       attn_launch_cfg<T, HD, 8, 64>(a, s);
+      return;
+    }
+  }
+  // CLIP ViT-L (257 tokens, head dim 64): 5 query blocks per head, each with ALL keys / values resident (5 tiles of 64,
+  // 138 KB) instead of streaming them tile by tile
+  if constexpr (sizeof(T) == 2 && HD == 64) {
+    static const bool no_res = getenv("ANYREF_ATTN_NO_RES64") != nullptr;
+    if (!no_res && a.Sq == a.Sk && a.Sk > 192 && a.Sk <= 320 && !a.causal && !a.kv_len && !a.q_len && !a.rel_h && !a.rel_p &&
+        !a.rel_tab_h) {
+      attn_launch_cfg<T, HD, 4, 64, 5>(a, s);
       return;
     }
   }
