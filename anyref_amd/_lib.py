@@ -87,6 +87,7 @@ SYMBOLS = {
     "anyref_op_sam_preprocess": (_I, [_P, _P, _I, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_float), _P]),
     "anyref_op_pil_resample_u8": (_I, [_P, _P, _I, _I, _I, _P, _P, _I, _I, _P, _P, _I, _P, _P, _I]),
     "anyref_op_pool_ref_tokens": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "anyref_op_kaldi_fbank": (_I, [_P, _P, _I, _I, _I, _I, _I, C.c_float, _P, _I, _P, _P, _I, C.c_float, C.c_float, _P]),
     "anyref_op_clip_finish": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_float), _P]),
     "anyref_op_gemv": (_I, [_I, _P, _P, _P, _F, _P, _P, _P, _P, _P, _I, _I, _I, _I]),
     "anyref_op_norm": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _F, _I]),

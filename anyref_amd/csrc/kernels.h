@@ -309,6 +309,12 @@ void launch_pil_resample_u8(const uint8_t* in, int H, int W, int C, uint8_t* tmp
                             hipStream_t s);
 void launch_clip_finish(const uint8_t* img, int ih, int iw, int y0, int x0, int h, int w, int S, const float* mean,
                         const float* std_, float* out, hipStream_t s);
+// Kaldi log-mel filterbank of one clip + pad / cut to target_len + Normalize (data.py:28-64,152-153): wave f32 [C, T] dev
+// (channel 0 is analysed, the clip mean is over all channels), banks f32 [n_mel, padded / 2 + 1] dev, tw f64 [2 * padded] dev
+// (cos then sin of 2 pi i / padded), scratch f64 [1] dev -> out f32 [n_mel, target_len] dev
+void launch_kaldi_fbank(const float* wave, int C, int T, int win, int shift, int padded, float preemph, const float* banks,
+                        int n_mel, const double* tw, double* scratch, int target_len, float mean, float stdv, float* out,
+                        hipStream_t s);
 void launch_sam_preprocess(const uint8_t* img, int h, int w, int S, const float* mean, const float* std_, float* out,
                            hipStream_t s);
 // per-row broadcast add: out[m,:] = a[m,:] + v[:]  (f32)

@@ -1300,4 +1300,108 @@ void launch_dequant_fp8_rows(const uint8_t* q, int ldq, const float* scale, int 
                      reinterpret_cast<bf16*>(out_bf16), ldo);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Audio front-end: Kaldi-compatible log-mel filterbank of one waveform clip, as
+// torchaudio.compliance.kaldi.fbank computes it for the options of model/ImageBind/data.py:28-64 (see
+// oracle/preprocess_oracle.py::kaldi_fbank for the restatement and what pins it), with the clip-mean removal in front
+// and the pad / cut to `target_len` frames + Normalize(mean, std) behind it fused in.
+// One workgroup per output frame column: 400 samples -> DC removal -> pre-emphasis -> Hann window -> zero pad to 512 ->
+// DFT by direct summation in f64 against a 512-entry twiddle table (198 frames x 257 bins x 400 taps: microseconds;
+// an FFT would buy nothing) -> power -> 128 triangular mel filters (f64 sums) -> log(max(., eps)) -> (x - mean) / std.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wave_sum_kernel(const float* __restrict__ w, int64_t n, double* __restrict__ out) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += 256) s += (double)w[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = red[0] + red[1] + red[2] + red[3];
+}
+
+template <int WIN, int PAD>
+__global__ __launch_bounds__(256) void kaldi_fbank_kernel(const float* __restrict__ wave, int T, int64_t n_all,
+                                                          const double* __restrict__ wsum, int shift, float preemph,
+                                                          const float* __restrict__ banks, int n_mel,
+                                                          const double* __restrict__ tw, int n_frames, int target_len,
+                                                          float mean, float stdv, float* __restrict__ out) {
+  constexpr int NB = PAD / 2 + 1;
+  __shared__ double tc[PAD], ts[PAD];
+  __shared__ double y[WIN];
+  __shared__ float pw[NB];
+  __shared__ double red[4];
+  const int f = blockIdx.x, tid = threadIdx.x;
+  if (f >= n_frames) {  // zero-padded frames: Normalize(0)
+    for (int b = tid; b < n_mel; b += 256) out[(int64_t)b * target_len + f] = (0.f - mean) / stdv;
+    return;
+  }
+  for (int i = tid; i < PAD; i += 256) {
+    tc[i] = tw[i];
+    ts[i] = tw[PAD + i];
+  }
+  const float gmean = (float)(wsum[0] / (double)n_all);  // waveform -= waveform.mean() (data.py:30), f32 like torch
+  // frame, DC removal (f64 mean of the f32 samples)
+  double part = 0.0;
+  for (int i = tid; i < WIN; i += 256) {
+    const double v = (double)(wave[(int64_t)f * shift + i] - gmean);
+    y[i] = v;
+    part += v;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+  if ((tid & 63) == 0) red[tid >> 6] = part;
+  __syncthreads();
+  const double fmean = (red[0] + red[1] + red[2] + red[3]) / (double)WIN;
+  // pre-emphasis on the DC-free frame (replicate pad: y[-1] = y[0]) and the Hann window, into registers first
+  double v0 = 0.0, v1 = 0.0;
+  {
+    const double PI2 = 6.283185307179586476925286766559;
+    const int i0 = tid, i1 = tid + 256;
+    if (i0 < WIN) {
+      const double cur = y[i0] - fmean, prev = y[i0 > 0 ? i0 - 1 : 0] - fmean;
+      v0 = (cur - (double)preemph * prev) * (0.5 - 0.5 * cos(PI2 * (double)i0 / (double)(WIN - 1)));
+    }
+    if (i1 < WIN) {
+      const double cur = y[i1] - fmean, prev = y[i1 - 1] - fmean;
+      v1 = (cur - (double)preemph * prev) * (0.5 - 0.5 * cos(PI2 * (double)i1 / (double)(WIN - 1)));
+    }
+  }
+  __syncthreads();
+  if (tid < WIN) y[tid] = v0;
+  if (tid + 256 < WIN) y[tid + 256] = v1;
+  __syncthreads();
+  // power spectrum: bin k = tid (and bin 256 on thread 0's second pass)
+  for (int k = tid; k < NB; k += 256) {
+    double re = 0.0, im = 0.0;
+    int idx = 0;  // (k * n) mod PAD
+    for (int n = 0; n < WIN; ++n) {
+      re += y[n] * tc[idx];
+      im -= y[n] * ts[idx];
+      idx = (idx + k) & (PAD - 1);
+    }
+    pw[k] = (float)(re * re + im * im);
+  }
+  __syncthreads();
+  for (int b = tid; b < n_mel; b += 256) {
+    const float* row = banks + (int64_t)b * NB;
+    double e = 0.0;
+    for (int k = 0; k < NB; ++k) e += (double)pw[k] * (double)row[k];
+    const float le = logf(fmaxf((float)e, 1.1920928955078125e-07f));
+    out[(int64_t)b * target_len + f] = (le - mean) / stdv;
+  }
+}
+
+void launch_kaldi_fbank(const float* wave, int C, int T, int win, int shift, int padded, float preemph, const float* banks,
+                        int n_mel, const double* tw, double* scratch, int target_len, float mean, float stdv, float* out,
+                        hipStream_t s) {
+  if (win != 400 || padded != 512) throw std::runtime_error("kaldi_fbank: built for 25 ms windows at 16 kHz (400 -> 512)");
+  if (C < 1 || T < 0 || n_mel < 1 || target_len < 1 || shift < 1) throw std::runtime_error("kaldi_fbank: bad sizes");
+  int n_frames = T < win ? 0 : 1 + (T - win) / shift;  // snip_edges
+  if (n_frames > target_len) n_frames = target_len;     // data.py:57-58 cuts
+  hipLaunchKernelGGL(wave_sum_kernel, dim3(1), dim3(256), 0, s, wave, (int64_t)C * T, scratch);
+  hipLaunchKernelGGL((kaldi_fbank_kernel<400, 512>), dim3(target_len), dim3(256), 0, s, wave, T, (int64_t)C * T, scratch,
+                     shift, preemph, banks, n_mel, tw, n_frames, target_len, mean, stdv, out);
+}
+
 }  // namespace anyref

@@ -152,6 +152,12 @@ int anyref_op_pool_ref_tokens(void* stream, const float* feats, int n, int L, in
   OP_GUARD(launch_pool_ref_tokens(feats, n, L, H, n_out, out, (hipStream_t)stream));
 }
 
+int anyref_op_kaldi_fbank(void* stream, const float* wave, int C, int T, int win, int shift, int padded, float preemph,
+                          const float* banks, int n_mel, const double* tw, double* scratch, int target_len, float mean,
+                          float stdv, float* out) {
+  OP_GUARD(launch_kaldi_fbank(wave, C, T, win, shift, padded, preemph, banks, n_mel, tw, scratch, target_len, mean, stdv, out,
+                              (hipStream_t)stream));
+}
 int anyref_op_clip_finish(void* stream, const uint8_t* img, int ih, int iw, int y0, int x0, int h, int w, int S,
                           const float* mean3, const float* std3, float* out) {
   OP_GUARD(launch_clip_finish(img, ih, iw, y0, x0, h, w, S, mean3, std3, out, (hipStream_t)stream));

@@ -1,4 +1,4 @@
-"""the host preprocessing right in front of the hot path, on the GPU.
+"""SURVEY.md §8 f-1 (and the audio front-end of f-4, at the end): the host preprocessing right in front of the hot path, on the GPU.
 
   * `resize_longest_side`  = `ResizeLongestSide.apply_image` (segment_anything/utils/transforms.py:27-34,102-113):
                              torchvision `resize(to_pil_image(img), (newh, neww))` = Pillow BILINEAR resample
@@ -145,3 +145,89 @@ def clip_image(image_hwc_u8: torch.Tensor, size: int = 224, resize_wo_crop: bool
     if rc != 0:
         raise RuntimeError("clip_finish: " + lib.anyref_op_last_error().decode())
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# SURVEY.md §8 f-4, the audio front-end in front of the ImageBind trunk (model/ImageBind/data.py:28-64,114-161):
+# waveform -> 3 clips of 2 s -> Kaldi log-mel filterbank (torchaudio.compliance.kaldi.fbank, the reference's options)
+# -> [mel, 204] padded / cut -> Normalize(-4.268, 9.138), one HIP launch pair per clip.  File decoding and resampling
+# to 16 kHz (torchaudio.load / functional.resample, data.py:133-137) stay with the caller.  No CPU fallback.
+# ---------------------------------------------------------------------------------------------------------------
+AUDIO_MEAN, AUDIO_STD = -4.268, 9.138          # data.py:121-122
+
+
+def kaldi_mel_banks(num_bins: int, padded_window: int, sample_freq: float, low_freq: float = 20.0,
+                    high_freq: float = 0.0) -> np.ndarray:
+    """torchaudio.compliance.kaldi.get_mel_banks (no VTLN warp) + the zero Nyquist column fbank() pads on:
+    float32 [num_bins, padded_window / 2 + 1] (host; built in double, same operation order)."""
+    nfft = padded_window // 2
+    if high_freq <= 0.0:
+        high_freq += 0.5 * sample_freq
+    mel = lambda f: 1127.0 * np.log(1.0 + np.asarray(f, dtype=np.float64) / 700.0)
+    lo, hi = mel(low_freq), mel(high_freq)
+    delta = (hi - lo) / (num_bins + 1)
+    b = np.arange(num_bins, dtype=np.float64)[:, None]
+    left, center, right = lo + b * delta, lo + (b + 1) * delta, lo + (b + 2) * delta
+    m = mel(sample_freq / padded_window * np.arange(nfft, dtype=np.float64))[None, :]
+    banks = np.maximum(0.0, np.minimum((m - left) / (center - left), (right - m) / (right - center)))
+    return np.concatenate([banks, np.zeros((num_bins, 1))], axis=1).astype(np.float32)
+
+
+@lru_cache(maxsize=8)
+def _fbank_tables(num_bins, padded, sample_rate, device):
+    i = np.arange(padded, dtype=np.float64)
+    tw = np.concatenate([np.cos(2.0 * np.pi * i / padded), np.sin(2.0 * np.pi * i / padded)])
+    return (torch.from_numpy(kaldi_mel_banks(num_bins, padded, float(sample_rate))).to(device),
+            torch.from_numpy(tw).to(device))
+
+
+def waveform2melspec(waveform: torch.Tensor, sample_rate: int = 16000, num_mel_bins: int = 128, target_length: int = 204,
+                     mean: float = AUDIO_MEAN, std: float = AUDIO_STD) -> torch.Tensor:
+    """`waveform2melspec` + `Normalize(mean, std)` (data.py:28-64,152-153) of one clip: float32 [C, T] device waveform at
+    `sample_rate` -> float32 [1, num_mel_bins, target_length] on the device."""
+    if not waveform.is_cuda or waveform.dtype != torch.float32 or waveform.dim() != 2:
+        raise ValueError("waveform2melspec wants a float32 [C, T] device tensor (there is no CPU fallback)")
+    if sample_rate != 16000:
+        raise ValueError("the HIP filterbank is built for 16 kHz input (25 ms = 400 samples -> 512-point transform), "
+                         "the rate data.py:118 resamples to")
+    lib = _lib.load()
+    w = waveform.contiguous()
+    Cn, T = (int(v) for v in w.shape)
+    dev = w.device
+    banks, tw = _fbank_tables(num_mel_bins, 512, sample_rate, dev)
+    out = torch.empty(1, num_mel_bins, target_length, dtype=torch.float32, device=dev)
+    scratch = torch.empty(1, dtype=torch.float64, device=dev)
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    rc = lib.anyref_op_kaldi_fbank(st, _ptr(w), Cn, T, 400, 160, 512, C.c_float(0.97), _ptr(banks), num_mel_bins, _ptr(tw),
+                                   _ptr(scratch), target_length, C.c_float(mean), C.c_float(std), _ptr(out))
+    if rc != 0:
+        raise RuntimeError("kaldi_fbank: " + lib.anyref_op_last_error().decode())
+    return out
+
+
+def constant_clip_timepoints(duration: float, clip_duration: float = 2.0, clips_per_video: int = 3):
+    """pytorchvideo `ConstantClipsPerVideoSampler(clip_duration, clips_per_video)` as `get_clip_timepoints`
+    (data.py:66-75) drives it: evenly spread (start, end) seconds, exact rational arithmetic."""
+    from fractions import Fraction
+    dur, clip = Fraction(duration), Fraction(clip_duration)
+    step = max(dur - clip, 0) / max(clips_per_video - 1, 1)
+    return [(float(step * i), float(step * i + clip)) for i in range(clips_per_video)]
+
+
+def load_and_transform_audio_data(waveforms, device=None, num_mel_bins: int = 128, target_length: int = 204,
+                                  sample_rate: int = 16000, clip_duration: float = 2, clips_per_video: int = 3,
+                                  mean: float = AUDIO_MEAN, std: float = AUDIO_STD) -> torch.Tensor:
+    """`load_and_transform_audio_data` (data.py:114-161) with decoded waveforms in place of paths: a list of float32
+    [C, T] tensors already at `sample_rate` -> float32 [len, clips_per_video, 1, num_mel_bins, target_length] on the device
+    (the `audios` item the model takes: [1, 3, 1, 128, 204])."""
+    if waveforms is None:
+        return None
+    outs = []
+    for w in waveforms:
+        w = w.to(device if device is not None else w.device, dtype=torch.float32)
+        clips = []
+        for t0, t1 in constant_clip_timepoints(w.shape[1] / sample_rate, clip_duration, clips_per_video):
+            clip = w[:, int(t0 * sample_rate): int(t1 * sample_rate)]
+            clips.append(waveform2melspec(clip, sample_rate, num_mel_bins, target_length, mean, std))
+        outs.append(torch.stack(clips, dim=0))
+    return torch.stack(outs, dim=0)

@@ -74,6 +74,15 @@ int anyref_op_pool_ref_tokens(void* stream, const float* feats, int n, int L, in
  * (align_corners = False) to out f32 CHW [3, S, S] dev.  mean3 / std3 are HOST pointers. */
 int anyref_op_clip_finish(void* stream, const uint8_t* img, int ih, int iw, int y0, int x0, int h, int w, int S,
                           const float* mean3, const float* std3, float* out);
+/* SURVEY.md §8 f-4, the audio front-end in front of the ImageBind trunk: replaces `waveform2melspec` + `Normalize`
+ * (model/ImageBind/data.py:28-64,152-153; torchaudio.compliance.kaldi.fbank with htk_compat, hanning window, 25 ms / 10 ms
+ * frames, no dither, 0.97 pre-emphasis, DC removal, power spectrum, log) for ONE clip: wave f32 [C, T] dev (channel 0
+ * is analysed, the clip mean is taken over all channels), banks f32 [n_mel, padded / 2 + 1] dev (kaldi mel filters + zero
+ * Nyquist column), tw f64 [2 * padded] dev (cos, then sin, of 2 pi i / padded), scratch f64 [1] dev -> out f32
+ * [n_mel, target_len] dev = (pad_or_cut(log-mel^T) - mean) / std.  win / padded: 400 / 512 (16 kHz). */
+int anyref_op_kaldi_fbank(void* stream, const float* wave, int C, int T, int win, int shift, int padded, float preemph,
+                          const float* banks, int n_mel, const double* tw, double* scratch, int target_len, float mean,
+                          float stdv, float* out);
 /* bf16 window attention with the decomposed rel-pos bias computed inside the kernel from the tables
  * (image_encoder.py:321-392 get_rel_pos / add_decomposed_rel_pos): tab_h bf16 [2*kh-1, hd], tab_w bf16 [2*kw-1, hd],
  * rows at stride tab_ld elements; S = kh*kw tokens, [B,S,H,hd] operands.  Only the shapes the resident-key form

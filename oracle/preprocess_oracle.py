@@ -9,6 +9,9 @@ The arithmetic lives in un-vendored third-party code the reference calls:
 Pillow's published algorithm (src/libImaging/Resample.c; Pillow 12.2.0 is what this image has) is restated below in
 numpy integers.  Pinned by `tests/golden/preprocess_pil.npz`: outputs of Pillow / the HF image processor / torch
 themselves, made by `tests/golden/make_golden_preprocess.py` in the build container.
+
+The audio front-end at the end of the file (model/ImageBind/data.py:28-64,114-161) is PARITY UNPINNED:
+torchaudio 0.13.0 and pytorchvideo are not installed here and the reference holds no fixture for it (see the section header).
 """
 from __future__ import annotations
 
@@ -116,3 +119,96 @@ def clip_preprocess(img: np.ndarray, size: int = 224, resize_wo_crop: bool = Tru
     if resize_wo_crop:
         x = F.interpolate(x[None], size=(size, size), mode="bilinear", align_corners=False)[0]
     return x
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Audio front-end: waveform -> normalised log-mel clips, model/ImageBind/data.py:28-64,114-161.
+#
+# PARITY UNPINNED: the arithmetic lives in two third-party packages the build container does not have --
+# torchaudio==0.13.0 (requirements.txt:26; `torchaudio.compliance.kaldi.fbank`, a restatement of Kaldi's
+# feature-fbank) and pytorchvideo @ 28fe037 (requirements.txt:17; `ConstantClipsPerVideoSampler`) -- and the reference
+# holds no fixture for it.  What follows restates their published algorithms for exactly the options the reference's
+# call site passes (data.py:31-41: htk_compat=True, use_energy=False, window_type="hanning", dither=0.0,
+# frame_length=25, frame_shift=10; everything else at torchaudio's defaults: preemphasis 0.97, remove_dc_offset,
+# round_to_power_of_two, snip_edges, low_freq 20, high_freq 0 -> Nyquist, use_power, use_log_fbank, no VTLN warp).
+# Accumulations are float64 here (torch: float32 rfft / mm); tests hold the GPU path to 1e-4 on the normalised log-mel.
+# ---------------------------------------------------------------------------------------------------------------
+KALDI_EPS = float(np.finfo(np.float32).eps)  # torchaudio _get_epsilon: torch.finfo(torch.float32).eps
+
+
+def kaldi_mel_banks(num_bins: int, padded_window: int, sample_freq: float, low_freq: float = 20.0, high_freq: float = 0.0):
+    """torchaudio.compliance.kaldi.get_mel_banks (vtln_warp = 1): [num_bins, padded_window / 2 + 1] float32 with the
+    zero Nyquist column fbank() pads on (compliance/kaldi.py: `mel_energies = pad(mel_energies, (0, 1))`)."""
+    nfft = padded_window // 2
+    nyquist = 0.5 * sample_freq
+    if high_freq <= 0.0:
+        high_freq += nyquist
+    mel = lambda f: 1127.0 * np.log(1.0 + np.asarray(f, dtype=np.float64) / 700.0)
+    mel_low, mel_high = mel(low_freq), mel(high_freq)
+    delta = (mel_high - mel_low) / (num_bins + 1)
+    b = np.arange(num_bins, dtype=np.float64)[:, None]
+    left, center, right = mel_low + b * delta, mel_low + (b + 1) * delta, mel_low + (b + 2) * delta
+    m = mel(sample_freq / padded_window * np.arange(nfft, dtype=np.float64))[None, :]
+    up, down = (m - left) / (center - left), (right - m) / (right - center)
+    banks = np.maximum(0.0, np.minimum(up, down))
+    return np.concatenate([banks, np.zeros((num_bins, 1))], axis=1).astype(np.float32)
+
+
+def kaldi_fbank(waveform: np.ndarray, sample_rate: int = 16000, num_mel_bins: int = 128, frame_length_ms: float = 25.0,
+                frame_shift_ms: float = 10.0, preemphasis: float = 0.97) -> np.ndarray:
+    """torchaudio.compliance.kaldi.fbank for the reference's options: waveform [C, T] (channel 0 is used) ->
+    [num_frames, num_mel_bins] float32 log-mel energies."""
+    x = np.asarray(waveform, dtype=np.float32)[0].astype(np.float64)
+    shift = int(sample_rate * frame_shift_ms * 0.001)
+    win = int(sample_rate * frame_length_ms * 0.001)
+    padded = 1 << (win - 1).bit_length()                      # round_to_power_of_two
+    if x.shape[0] < win:
+        return np.zeros((0, num_mel_bins), dtype=np.float32)
+    m = 1 + (x.shape[0] - win) // shift                       # snip_edges
+    idx = np.arange(m)[:, None] * shift + np.arange(win)[None, :]
+    fr = x[idx]
+    fr = fr - fr.mean(axis=1, keepdims=True)                  # remove_dc_offset
+    prev = np.concatenate([fr[:, :1], fr[:, :-1]], axis=1)    # replicate-padded shift by one
+    fr = fr - preemphasis * prev
+    n = np.arange(win, dtype=np.float64)
+    fr = fr * (0.5 - 0.5 * np.cos(2.0 * np.pi * n / (win - 1)))   # torch.hann_window(win, periodic=False)
+    fr = np.concatenate([fr, np.zeros((m, padded - win))], axis=1)
+    power = np.abs(np.fft.rfft(fr, axis=1)) ** 2
+    mel = power @ kaldi_mel_banks(num_mel_bins, padded, float(sample_rate)).astype(np.float64).T
+    return np.log(np.maximum(mel, KALDI_EPS)).astype(np.float32)
+
+
+def waveform2melspec(waveform: np.ndarray, sample_rate: int, num_mel_bins: int, target_length: int) -> np.ndarray:
+    """data.py:28-64: subtract the clip mean (all channels), fbank, transpose, zero-pad / cut to target_length ->
+    [1, num_mel_bins, target_length]."""
+    w = np.asarray(waveform, dtype=np.float32)
+    w = w - w.mean(dtype=np.float64).astype(np.float32)
+    fb = kaldi_fbank(w, sample_rate, num_mel_bins).T
+    p = target_length - fb.shape[1]
+    if p > 0:
+        fb = np.pad(fb, ((0, 0), (0, p)))
+    elif p < 0:
+        fb = fb[:, :target_length]
+    return fb[None]
+
+
+def constant_clip_timepoints(duration: float, clip_duration: float = 2.0, clips_per_video: int = 3):
+    """pytorchvideo ConstantClipsPerVideoSampler driven by data.py:66-75: `clips_per_video` windows of `clip_duration`
+    seconds spread evenly over [0, duration] (exact rational arithmetic, as the sampler's Fractions)."""
+    from fractions import Fraction
+    dur, clip = Fraction(duration), Fraction(clip_duration)
+    max_start = max(dur - clip, 0)
+    step = max_start / max(clips_per_video - 1, 1)
+    return [(float(step * i), float(step * i + clip)) for i in range(clips_per_video)]
+
+
+def load_and_transform_audio(waveform: np.ndarray, sample_rate: int = 16000, num_mel_bins: int = 128,
+                             target_length: int = 204, clip_duration: float = 2.0, clips_per_video: int = 3,
+                             mean: float = -4.268, std: float = 9.138) -> np.ndarray:
+    """data.py:114-161 from an in-memory waveform [C, T] already at `sample_rate` (file decoding and resampling are the
+    caller's): -> [clips_per_video, 1, num_mel_bins, target_length] float32, Normalize(mean, std) applied."""
+    out = []
+    for t0, t1 in constant_clip_timepoints(waveform.shape[1] / sample_rate, clip_duration, clips_per_video):
+        clip = waveform[:, int(t0 * sample_rate): int(t1 * sample_rate)]
+        out.append((waveform2melspec(clip, sample_rate, num_mel_bins, target_length) - np.float32(mean)) / np.float32(std))
+    return np.stack(out).astype(np.float32)

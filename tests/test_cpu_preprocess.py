@@ -47,3 +47,46 @@ def test_product_coefficient_tables_equal_the_scalar_restatement(filt, sizes):
     b2, k2 = PO.precompute_coeffs(sizes[0], sizes[1], filt)
     assert np.array_equal(b, b2) and np.array_equal(k, k2)
     assert get_preprocess_shape(480, 640, 1024) == PO.get_preprocess_shape(480, 640, 1024) == (768, 1024)
+
+
+def test_audio_front_end_oracle_properties():
+    """The numpy restatement of the audio front-end (model/ImageBind/data.py:28-64,114-161; torchaudio 0.13.0 kaldi.fbank +
+    pytorchvideo's clip sampler, neither installed here: PARITY UNPINNED) against what the published algorithm implies:
+    frame count under snip_edges, the padded frames after Normalize, DC / constant-offset invariance, a pure tone landing in
+    the mel filter that covers it, the empty low filters at 128 bins / 512-point transform giving log(eps), and the sampler."""
+    from oracle import preprocess_oracle as PO
+    sr = 16000
+    rng = np.random.default_rng(7)
+    w = (rng.standard_normal((1, 2 * sr)) * 0.1).astype(np.float32)
+    fb = PO.kaldi_fbank(w, sr)
+    assert fb.shape == (1 + (2 * sr - 400) // 160, 128) == (198, 128)
+    m = PO.waveform2melspec(w, sr, 128, 204)
+    assert m.shape == (1, 128, 204) and np.all(m[0, :, 198:] == 0.0)
+    assert np.abs(m[0, :, :198] - fb.T).max() < 2e-3                      # (the clip mean is removed first: f32 rounding of the input)
+    out = PO.load_and_transform_audio(w, sr)
+    assert out.shape == (3, 1, 128, 204)
+    assert np.allclose(out[0, 0, :, 198:], (0.0 + 4.268) / 9.138)          # zero-padded frames after Normalize
+    assert np.array_equal(out[0], out[1]) and np.array_equal(out[0], out[2])  # a 2 s waveform: three identical clips
+    # DC removal per frame: a constant offset changes nothing beyond f32 rounding of the input
+    fb_off = PO.kaldi_fbank(w + np.float32(0.25), sr)
+    assert np.abs(fb_off - fb).max() < 2e-3
+    # a constant signal has no energy after DC removal: every filter at log(eps)
+    const = PO.kaldi_fbank(np.full((1, sr), 0.5, dtype=np.float32), sr)
+    assert np.allclose(const, np.log(np.float32(PO.KALDI_EPS)))
+    # mel filters: triangles that tile [20 Hz, Nyquist]; the lowest are narrower than one FFT bin (31.25 Hz) and some are empty
+    banks = PO.kaldi_mel_banks(128, 512, float(sr))
+    assert banks.shape == (128, 257) and np.all(banks >= 0) and np.all(banks <= 1.0) and np.all(banks[:, 256] == 0)
+    empty = np.where(banks.sum(1) == 0)[0]
+    assert 0 < len(empty) < 8 and empty.max() < 16
+    assert np.allclose(fb[:, empty], np.log(np.float32(PO.KALDI_EPS)))
+    # 1 kHz tone: the strongest filter is the one whose triangle contains 1 kHz
+    t = np.arange(2 * sr) / sr
+    tone = PO.kaldi_fbank((0.5 * np.sin(2 * np.pi * 1000.0 * t))[None].astype(np.float32), sr)
+    peak = int(np.bincount(tone.argmax(1)).argmax())
+    mel = lambda f: 1127.0 * np.log(1.0 + f / 700.0)
+    delta = (mel(8000.0) - mel(20.0)) / 129
+    assert abs(peak - ((mel(1000.0) - mel(20.0)) / delta - 1)) <= 1.0
+    # the sampler: clips_per_video windows spread evenly, the last one ending at the end
+    assert PO.constant_clip_timepoints(5.0) == [(0.0, 2.0), (1.5, 3.5), (3.0, 5.0)]
+    assert PO.constant_clip_timepoints(2.0) == [(0.0, 2.0)] * 3
+    assert PO.constant_clip_timepoints(1.0) == [(0.0, 2.0)] * 3             # shorter than a clip: the slice just ends early

@@ -59,3 +59,36 @@ def test_preprocess_refusals():
         pil_resize_u8(torch.zeros(4, 4, 3, dtype=torch.uint8), (2, 2))        # host tensor: no CPU fallback
     with pytest.raises(ValueError):
         pil_resize_u8(torch.zeros(4, 4, 3).cuda(), (2, 2))                     # not uint8
+
+
+@pytest.mark.parametrize("case", ["noise 5 s stereo", "tone + noise 2.0 s", "short 1.3 s", "long 9.7 s, DC offset"])
+def test_audio_front_end_vs_oracle(case):
+    """`load_and_transform_audio_data` / `waveform2melspec` (model/ImageBind/data.py:28-64,114-161) on the device against the
+    numpy restatement of torchaudio.compliance.kaldi.fbank + the clip sampler (oracle/preprocess_oracle.py; PARITY
+    UNPINNED: torchaudio 0.13.0 and pytorchvideo are not in the build container, the reference holds no fixture).
+    Tolerance 1e-4 on the normalised log-mel (values in [-1.5, 1.5]; f64 sums on both sides, f32 log): clip mean
+    removal over all channels, channel 0 analysed, 198 frames of a 2 s clip padded to 204 with Normalize(0), a clip
+    shorter than 2 s (fewer frames), a long waveform (three spread clips), empty mel bins (log eps)."""
+    from anyref_amd.preprocess import load_and_transform_audio_data, waveform2melspec
+    from oracle import preprocess_oracle as PO
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(case.encode()))
+    sr = 16000
+    if case.startswith("noise"):
+        w = (rng.standard_normal((2, 5 * sr)) * 0.1).astype(np.float32)
+    elif case.startswith("tone"):
+        t = np.arange(2 * sr) / sr
+        w = (0.3 * np.sin(2 * np.pi * 440.0 * t) + 0.01 * rng.standard_normal(2 * sr))[None].astype(np.float32)
+    elif case.startswith("short"):
+        w = (rng.standard_normal((1, int(1.3 * sr))) * 0.05).astype(np.float32)
+    else:
+        w = (rng.standard_normal((1, int(9.7 * sr))) * 0.2 + 0.35).astype(np.float32)
+    ref = PO.load_and_transform_audio(w, sr)
+    got = load_and_transform_audio_data([torch.from_numpy(w).cuda()])
+    assert got.shape == (1, 3, 1, 128, 204) and got.dtype == torch.float32
+    err = np.abs(got[0].cpu().numpy() - ref).max()
+    print(f"    {case}: max abs err {err:.2e} on normalised log-mel in [{ref.min():.2f}, {ref.max():.2f}]")
+    assert err <= 1e-4, (case, err)
+    one = waveform2melspec(torch.from_numpy(w[:, : 2 * sr]).cuda())
+    ref1 = (PO.waveform2melspec(w[:, : 2 * sr], sr, 128, 204) - np.float32(-4.268)) / np.float32(9.138)
+    assert np.abs(one.cpu().numpy() - ref1).max() <= 1e-4
