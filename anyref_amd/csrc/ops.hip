@@ -566,10 +566,68 @@ __global__ void rope_cache_kernel(const TIN* __restrict__ qkv, int B, int S, int
     vc[co + d + half] = from_f32<T>(v2);
   }
 }
+// bf16 rows, 16-byte accesses: a lane takes 8 consecutive d of the first half and the 8 partners of the second half
+// (six 16-byte loads, six stores) -- the same f32 operations as the scalar kernel above, bit-identical results.
+__global__ __launch_bounds__(256) void rope_cache_vec_kernel(const bf16* __restrict__ qkv, int S, int H, int hd,
+                                                             const int* __restrict__ pos0, const int* __restrict__ lens,
+                                                             const float* __restrict__ cs_tab, bf16* __restrict__ q_out,
+                                                             bf16* __restrict__ kc, bf16* __restrict__ vc, int maxS,
+                                                             bf16* __restrict__ q_keep) {
+  const int srow = blockIdx.x, b = blockIdx.y;
+  if (lens && srow >= lens[b]) return;
+  const int pos = (pos0 ? pos0[b] : 0) + srow;
+  const int half = hd / 2, per = half / 8;  // lanes per head
+  const bf16* base = qkv + ((int64_t)b * S + srow) * 3 * H * hd;
+  for (int i = threadIdx.x; i < H * per; i += blockDim.x) {
+    const int h = i / per, d = (i % per) * 8;
+    float cs[8], sn[8];
+    *reinterpret_cast<float4v*>(cs) = *reinterpret_cast<const float4v*>(cs_tab + ((int64_t)pos * 2) * half + d);
+    *reinterpret_cast<float4v*>(cs + 4) = *reinterpret_cast<const float4v*>(cs_tab + ((int64_t)pos * 2) * half + d + 4);
+    *reinterpret_cast<float4v*>(sn) = *reinterpret_cast<const float4v*>(cs_tab + ((int64_t)pos * 2 + 1) * half + d);
+    *reinterpret_cast<float4v*>(sn + 4) = *reinterpret_cast<const float4v*>(cs_tab + ((int64_t)pos * 2 + 1) * half + d + 4);
+    float q1[8], q2[8], k1[8], k2[8];
+    Vec16<bf16>::unpack(*reinterpret_cast<const uint4v*>(base + h * hd + d), q1);
+    Vec16<bf16>::unpack(*reinterpret_cast<const uint4v*>(base + h * hd + d + half), q2);
+    Vec16<bf16>::unpack(*reinterpret_cast<const uint4v*>(base + (H + h) * hd + d), k1);
+    Vec16<bf16>::unpack(*reinterpret_cast<const uint4v*>(base + (H + h) * hd + d + half), k2);
+    const uint4v v1 = *reinterpret_cast<const uint4v*>(base + (2 * H + h) * hd + d);
+    const uint4v v2 = *reinterpret_cast<const uint4v*>(base + (2 * H + h) * hd + d + half);
+    bf16 qa[8], qb[8], ka[8], kb[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      qa[e] = from_f32<bf16>(q1[e] * cs[e] - q2[e] * sn[e]);
+      qb[e] = from_f32<bf16>(q2[e] * cs[e] + q1[e] * sn[e]);
+      ka[e] = from_f32<bf16>(k1[e] * cs[e] - k2[e] * sn[e]);
+      kb[e] = from_f32<bf16>(k2[e] * cs[e] + k1[e] * sn[e]);
+    }
+    bf16* qo = q_out + (((int64_t)b * S + srow) * H + h) * hd;
+    *reinterpret_cast<uint4v*>(qo + d) = *reinterpret_cast<const uint4v*>(qa);
+    *reinterpret_cast<uint4v*>(qo + d + half) = *reinterpret_cast<const uint4v*>(qb);
+    const int64_t co = (((int64_t)b * maxS + pos) * H + h) * hd;
+    if (q_keep) {
+      *reinterpret_cast<uint4v*>(q_keep + co + d) = *reinterpret_cast<const uint4v*>(qa);
+      *reinterpret_cast<uint4v*>(q_keep + co + d + half) = *reinterpret_cast<const uint4v*>(qb);
+    }
+    *reinterpret_cast<uint4v*>(kc + co + d) = *reinterpret_cast<const uint4v*>(ka);
+    *reinterpret_cast<uint4v*>(kc + co + d + half) = *reinterpret_cast<const uint4v*>(kb);
+    *reinterpret_cast<uint4v*>(vc + co + d) = v1;
+    *reinterpret_cast<uint4v*>(vc + co + d + half) = v2;
+  }
+}
 template <typename T>
 void launch_rope_cache(const void* qkv, int B, int S, int H, int hd, const int* pos0, const int* lens,
                        const float* cs_tab, void* q_out, void* kc, void* vc, int maxS, void* q_keep,
                        hipStream_t s) {
+  if constexpr (sizeof(T) == 2) {
+    const bool al = !(((uintptr_t)qkv | (uintptr_t)q_out | (uintptr_t)kc | (uintptr_t)vc | (uintptr_t)q_keep |
+                       (uintptr_t)cs_tab) & 15);
+    if (hd % 16 == 0 && al) {
+      hipLaunchKernelGGL(rope_cache_vec_kernel, dim3(S, B), dim3(256), 0, s, reinterpret_cast<const bf16*>(qkv), S, H, hd,
+                         pos0, lens, cs_tab, reinterpret_cast<bf16*>(q_out), reinterpret_cast<bf16*>(kc),
+                         reinterpret_cast<bf16*>(vc), maxS, reinterpret_cast<bf16*>(q_keep));
+      return;
+    }
+  }
   hipLaunchKernelGGL((rope_cache_kernel<T, T>), dim3(S, B), dim3(256), 0, s, reinterpret_cast<const T*>(qkv), B,
                      S, H, hd, pos0, lens, cs_tab, reinterpret_cast<T*>(q_out), reinterpret_cast<T*>(kc),
                      reinterpret_cast<T*>(vc), maxS, reinterpret_cast<T*>(q_keep));
