@@ -57,6 +57,19 @@ template <>
 __device__ inline bf16 from_f32<bf16>(float v) {
   return f2bf(v);
 }
+// four consecutive outputs as ONE store (p: 8-byte aligned for bf16, 16-byte for f32); same rounding as from_f32
+template <typename T>
+__device__ inline void store4_from_f32(T* p, float a, float b, float c, float d);
+template <>
+__device__ inline void store4_from_f32<float>(float* p, float a, float b, float c, float d) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  *reinterpret_cast<f4*>(p) = f4{a, b, c, d};
+}
+template <>
+__device__ inline void store4_from_f32<bf16>(bf16* p, float a, float b, float c, float d) {
+  typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+  *reinterpret_cast<u2*>(p) = u2{(uint32_t)f2bf(a).x | ((uint32_t)f2bf(b).x << 16), (uint32_t)f2bf(c).x | ((uint32_t)f2bf(d).x << 16)};
+}
 
 // ---- vector types --------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(8))) short short8;   // 8 x bf16 = one MFMA A/B fragment

@@ -662,10 +662,7 @@ __global__ __launch_bounds__(NT) void splitk_reduce_norm_kernel(const float* __r
       const float4v g = *reinterpret_cast<const float4v*>(a.norm_gain + n);
       float4v o = v[i] * scale * g;
       if (a.norm_bias) o += *reinterpret_cast<const float4v*>(a.norm_bias + n);
-      y[n] = from_f32<T>(o[0]);
-      y[n + 1] = from_f32<T>(o[1]);
-      y[n + 2] = from_f32<T>(o[2]);
-      y[n + 3] = from_f32<T>(o[3]);
+      store4_from_f32<T>(y + n, o[0], o[1], o[2], o[3]);
     }
   }
 }

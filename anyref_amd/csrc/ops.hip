@@ -217,8 +217,7 @@ __global__ __launch_bounds__(256) void norm_wide_kernel(NormArgs a) {
     if (a.y_f32) {
       *reinterpret_cast<float4v*>(yf + 4 * j) = o;
     } else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) yt[4 * j + e] = from_f32<T>(o[e]);
+      store4_from_f32<T>(yt + 4 * j, o[0], o[1], o[2], o[3]);
     }
   }
 }
