@@ -735,6 +735,20 @@ void launch_gemm(const GemmArgs& a_in, hipStream_t s) {
   if (a.swiglu_pairs && (a.N % 4 || a.bias || a.resid || a.row_map || a.act != ACT_NONE || a.batch != 1))
     throw std::runtime_error("gemm: the SwiGLU epilogue takes interleaved gate/up rows, N % 4 == 0, and nothing else");
   constexpr int VEC = Mma<T>::VEC;
+  if (a.slabs_out && a.slabs > 1) {  // raw split-K: the consumer sums the slices
+    if (sizeof(T) != 2 || a.batch != 1 || a.row_map || a.bias || a.resid || a.act != ACT_NONE || a.swiglu_pairs || a.w_fp8 ||
+        a.K % (64 * a.slabs))
+      throw std::runtime_error("gemm: raw split-K slabs take a plain bf16 product with K % (64 * slabs) == 0");
+    GemmArgs g = a;
+    g.K = a.K / a.slabs;
+    g.batch = a.slabs;
+    g.sA = g.K;
+    g.sW = g.K;
+    g.C = a.slabs_out; g.ldc = a.N; g.sC = (int64_t)a.M * a.N; g.c_f32 = 1;
+    g.slabs_out = nullptr; g.slabs = 0; g.norm_out = nullptr;
+    launch_gemm<T>(g, s);
+    return;
+  }
   // ---- split-K decision: few 64x64 tiles, deep K, plain row-major output ----
   // (K >= 1024 when a norm rides on the reduction: CLIP out_proj, 24 tiles of 16 K steps + a LayerNorm launch otherwise)
   if (!knobs().no_splitk && sizeof(T) == 2 && a.batch == 1 && !a.row_map && a.M <= 512 &&
@@ -912,6 +926,10 @@ void launch_gemm(const GemmArgs& a_in, hipStream_t s) {
       else if (!a.w_fp8 && knobs().m320 >= 0 && a.M > 192 && a.M <= 320 && a.N >= 16384 && a.batch == 1 && cdiv(a.N, 96) <= cus)
         // prefill gate/up (320 x 22016 x 4096): every workgroup owns a weight panel outright (all of M in one
         // tile, 230 panels on 256 CUs) instead of five 64-row workgroups sharing one: 7 % faster from cold weights
+        go(I320(), std::integral_constant<int, 96>(), I4(), I2(), I2(), "gemm_bf16_320x96");
+      else if (!a.w_fp8 && knobs().m320 >= 0 && a.M > 192 && a.M <= 320 && a.batch == 2 && a.N >= 8192 &&
+               (int64_t)cdiv(a.N, 96) * 2 <= cus)
+        // prefill qkv as two K slices (128 panels x 2 = 256 workgroups, a panel per workgroup); the RoPE kernel adds them
         go(I320(), std::integral_constant<int, 96>(), I4(), I2(), I2(), "gemm_bf16_320x96");
       else if (!a.w_fp8 && knobs().m320 >= 0 && a.M > 192 && a.M <= 320 && a.batch > 1 && (int64_t)cdiv(a.N, 64) * a.batch <= cus &&
                (int64_t)cdiv(a.N, 64) * a.batch * 4 >= cus * 3)  // (CLIP fc2's 128 slabs stay on 128^2 tiles: 192 workgroups)

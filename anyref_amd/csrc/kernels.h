@@ -93,6 +93,10 @@ struct GemmArgs {
   int norm_ld = 0;
   float norm_eps = 0.f;
   const float* norm_bias = nullptr;  // set: LayerNorm (mean removed, + bias) instead of RMSNorm
+  // raw split-K: `slabs` K slices summed by the CONSUMER -- C is ignored, slice z goes to slabs_out + z * M * N (f32,
+  // row stride N).  No bias / activation / residual.  (prefill qkv: the RoPE + cache kernel adds the two slices.)
+  float* slabs_out = nullptr;
+  int slabs = 0;
   bool* norm_done = nullptr;
   // optional batching over blockIdx.z (element strides)
   int batch = 1;
@@ -255,6 +259,10 @@ void launch_scatter_rows(const float* rows, const int* dst_b, const int* dst_pos
 // RoPE (rotate_half form) on q,k of a fused qkv buffer + append k,v to the cache.
 // qkv T [B,S,3,H,hd]; pos0 i32 [B] dev; q_out T [B,S,H,hd]; kc/vc T [B,maxS,H,hd];
 // cs_tab f32 [maxS][2][hd/2] = cos | sin of pos * inv_freq (built on the host like HF does)
+// same from two f32 split-K slices of the projection (slab0 + slab1, rounded to bf16 first like the GEMM's own output)
+void launch_rope_cache_slabs(const float* slab0, const float* slab1, int B, int S, int H, int hd, const int* pos0,
+                             const int* lens, const float* cs_tab, void* q_out, void* kc, void* vc, int maxS, void* q_keep,
+                             hipStream_t s);
 template <typename T>
 void launch_rope_cache(const void* qkv, int B, int S, int H, int hd, const int* pos0, const int* lens,
                        const float* cs_tab, void* q_out, void* kc, void* vc, int maxS, void* q_keep,

@@ -350,6 +350,8 @@ class Model : public ModelBase {
   float *d_x_ = nullptr, *d_qkv_ = nullptr, *d_att_ = nullptr, *d_act_ = nullptr;
   T* d_q_ = nullptr;
   int64_t *ids_dev_ = nullptr, *next_dev_ = nullptr;
+  float* qkv_slabs_ = nullptr;  // [2][<= 320][3H] f32: the two K slices of the prefill qkv projection
+  bool qkv_slabs_off_ = getenv("ANYREF_NO_QKV_SLABS") != nullptr;
   int *lens_dev_ = nullptr, *slen_dev_ = nullptr, *pos_dev_ = nullptr, *kvlen_dev_ = nullptr, *rowmap_dev_ = nullptr,
       *idx_a_ = nullptr, *idx_b_ = nullptr;
   int64_t* next_host_ = nullptr;  // pinned, two slots of max_batch tokens (the greedy loop runs one step ahead)
@@ -626,6 +628,7 @@ void Model<T>::finalize() {
     hidden_all_ = talloc<float>(R * H);
     l_h_ = talloc<T>(R * H);
     l_qkv_ = talloc<T>(R * 3 * H);
+    if (sizeof(T) == 2 && (size_t)3 * H / 96 * 2 <= 256) qkv_slabs_ = talloc<float>((size_t)2 * 320 * 3 * H);  // prefill qkv K slices (R <= 320)
     l_q_ = talloc<T>(R * H);
     l_att_ = talloc<T>(R * H);
     l_act_ = talloc<T>(R * F);
@@ -1113,9 +1116,19 @@ void Model<T>::llm_prefill(hipStream_t s, int B, int Sp, const int* lens_dev, bo
     T* kc = kcache_ + cache_layer_stride_ * i;
     T* vc = vcache_ + cache_layer_stride_ * i;
     if (!h_ready) norm(s, l_x_, H, L.in_norm, l_h_, H, R, H, c.llm_rms_eps, false, true);
-    gemm(s, l_h_, H, L.qkv, l_qkv_, 3 * H, R, ACT_NONE, false);
-    launch_rope_cache<T>(l_qkv_, B, Sp, nh, hd, nullptr, lens_dev, rope_tab_, l_q_, kc, vc, S,
-                         (keep_q && i == nl - 1) ? q_last_ : nullptr, s);
+    T* qkeep = (keep_q && i == nl - 1) ? q_last_ : nullptr;
+    if (qkv_slabs_ && !L.qkv.w8 && R > 192 && R <= 320 && H % 128 == 0 && hd % 16 == 0 && !qkv_slabs_off_) {
+      // one image's prompt: the projection as two K slices on whole-M tiles (256 workgroups), summed by the RoPE kernel
+      GemmArgs a;
+      a.A = l_h_; a.lda = H; a.W = L.qkv.w; a.ldw = L.qkv.stride(); a.M = R; a.N = 3 * H; a.K = H;
+      a.slabs_out = qkv_slabs_; a.slabs = 2;
+      launch_gemm<T>(a, s);
+      launch_rope_cache_slabs(qkv_slabs_, qkv_slabs_ + (size_t)R * 3 * H, B, Sp, nh, hd, nullptr, lens_dev, rope_tab_, l_q_, kc,
+                              vc, S, qkeep, s);
+    } else {
+      gemm(s, l_h_, H, L.qkv, l_qkv_, 3 * H, R, ACT_NONE, false);
+      launch_rope_cache<T>(l_qkv_, B, Sp, nh, hd, nullptr, lens_dev, rope_tab_, l_q_, kc, vc, S, qkeep, s);
+    }
     AttnArgs a;
     a.Q = l_q_; a.K = kc; a.V = vc; a.O = l_att_;
     a.q_bs = (int64_t)Sp * H; a.q_rs = H; a.q_hs = hd;

@@ -567,7 +567,9 @@ __global__ void rope_cache_kernel(const TIN* __restrict__ qkv, int B, int S, int
 }
 // bf16 rows, 16-byte accesses: a lane takes 8 consecutive d of the first half and the 8 partners of the second half
 // (six 16-byte loads, six stores) -- the same f32 operations as the scalar kernel above, bit-identical results.
-__global__ __launch_bounds__(256) void rope_cache_vec_kernel(const bf16* __restrict__ qkv, int S, int H, int hd,
+template <bool SLABS>
+__global__ __launch_bounds__(256) void rope_cache_vec_kernel(const bf16* __restrict__ qkv, const float* __restrict__ slab0,
+                                                             const float* __restrict__ slab1, int S, int H, int hd,
                                                              const int* __restrict__ pos0, const int* __restrict__ lens,
                                                              const float* __restrict__ cs_tab, bf16* __restrict__ q_out,
                                                              bf16* __restrict__ kc, bf16* __restrict__ vc, int maxS,
@@ -576,7 +578,22 @@ __global__ __launch_bounds__(256) void rope_cache_vec_kernel(const bf16* __restr
   if (lens && srow >= lens[b]) return;
   const int pos = (pos0 ? pos0[b] : 0) + srow;
   const int half = hd / 2, per = half / 8;  // lanes per head
-  const bf16* base = qkv + ((int64_t)b * S + srow) * 3 * H * hd;
+  const int64_t roff = ((int64_t)b * S + srow) * 3 * H * hd;
+  const bf16* base = qkv + roff;
+  // 8 values at column c of this row: the GEMM's bf16 output, or the sum of its two f32 K slices rounded the same way
+  auto ld8 = [&](int c, float (&o)[8]) {
+    if constexpr (SLABS) {
+      const float4v a0 = *reinterpret_cast<const float4v*>(slab0 + roff + c), a1 = *reinterpret_cast<const float4v*>(slab0 + roff + c + 4);
+      const float4v b0 = *reinterpret_cast<const float4v*>(slab1 + roff + c), b1 = *reinterpret_cast<const float4v*>(slab1 + roff + c + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[e] = bf2f(f2bf(a0[e] + b0[e]));
+        o[4 + e] = bf2f(f2bf(a1[e] + b1[e]));
+      }
+    } else {
+      Vec16<bf16>::unpack(*reinterpret_cast<const uint4v*>(base + c), o);
+    }
+  };
   for (int i = threadIdx.x; i < H * per; i += blockDim.x) {
     const int h = i / per, d = (i % per) * 8;
     float cs[8], sn[8];
@@ -584,14 +601,19 @@ __global__ __launch_bounds__(256) void rope_cache_vec_kernel(const bf16* __restr
     *reinterpret_cast<float4v*>(cs + 4) = *reinterpret_cast<const float4v*>(cs_tab + ((int64_t)pos * 2) * half + d + 4);
     *reinterpret_cast<float4v*>(sn) = *reinterpret_cast<const float4v*>(cs_tab + ((int64_t)pos * 2 + 1) * half + d);
     *reinterpret_cast<float4v*>(sn + 4) = *reinterpret_cast<const float4v*>(cs_tab + ((int64_t)pos * 2 + 1) * half + d + 4);
-    float q1[8], q2[8], k1[8], k2[8];
-    Vec16<bf16>::unpack(*reinterpret_cast<const uint4v*>(base + h * hd + d), q1);
-    Vec16<bf16>::unpack(*reinterpret_cast<const uint4v*>(base + h * hd + d + half), q2);
-    Vec16<bf16>::unpack(*reinterpret_cast<const uint4v*>(base + (H + h) * hd + d), k1);
-    Vec16<bf16>::unpack(*reinterpret_cast<const uint4v*>(base + (H + h) * hd + d + half), k2);
-    const uint4v v1 = *reinterpret_cast<const uint4v*>(base + (2 * H + h) * hd + d);
-    const uint4v v2 = *reinterpret_cast<const uint4v*>(base + (2 * H + h) * hd + d + half);
-    bf16 qa[8], qb[8], ka[8], kb[8];
+    float q1[8], q2[8], k1[8], k2[8], va[8], vb[8];
+    ld8(h * hd + d, q1);
+    ld8(h * hd + d + half, q2);
+    ld8((H + h) * hd + d, k1);
+    ld8((H + h) * hd + d + half, k2);
+    ld8((2 * H + h) * hd + d, va);
+    ld8((2 * H + h) * hd + d + half, vb);
+    bf16 qa[8], qb[8], ka[8], kb[8], v1[8], v2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      v1[e] = from_f32<bf16>(va[e]);   // exact: va / vb are bf16 values
+      v2[e] = from_f32<bf16>(vb[e]);
+    }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       qa[e] = from_f32<bf16>(q1[e] * cs[e] - q2[e] * sn[e]);
@@ -609,8 +631,8 @@ __global__ __launch_bounds__(256) void rope_cache_vec_kernel(const bf16* __restr
     }
     *reinterpret_cast<uint4v*>(kc + co + d) = *reinterpret_cast<const uint4v*>(ka);
     *reinterpret_cast<uint4v*>(kc + co + d + half) = *reinterpret_cast<const uint4v*>(kb);
-    *reinterpret_cast<uint4v*>(vc + co + d) = v1;
-    *reinterpret_cast<uint4v*>(vc + co + d + half) = v2;
+    *reinterpret_cast<uint4v*>(vc + co + d) = *reinterpret_cast<const uint4v*>(v1);
+    *reinterpret_cast<uint4v*>(vc + co + d + half) = *reinterpret_cast<const uint4v*>(v2);
   }
 }
 template <typename T>
@@ -621,7 +643,8 @@ void launch_rope_cache(const void* qkv, int B, int S, int H, int hd, const int* 
     const bool al = !(((uintptr_t)qkv | (uintptr_t)q_out | (uintptr_t)kc | (uintptr_t)vc | (uintptr_t)q_keep |
                        (uintptr_t)cs_tab) & 15);
     if (hd % 16 == 0 && al) {
-      hipLaunchKernelGGL(rope_cache_vec_kernel, dim3(S, B), dim3(256), 0, s, reinterpret_cast<const bf16*>(qkv), S, H, hd,
+      hipLaunchKernelGGL(rope_cache_vec_kernel<false>, dim3(S, B), dim3(256), 0, s, reinterpret_cast<const bf16*>(qkv),
+                         (const float*)nullptr, (const float*)nullptr, S, H, hd,
                          pos0, lens, cs_tab, reinterpret_cast<bf16*>(q_out), reinterpret_cast<bf16*>(kc),
                          reinterpret_cast<bf16*>(vc), maxS, reinterpret_cast<bf16*>(q_keep));
       return;
@@ -630,6 +653,16 @@ void launch_rope_cache(const void* qkv, int B, int S, int H, int hd, const int* 
   hipLaunchKernelGGL((rope_cache_kernel<T, T>), dim3(S, B), dim3(256), 0, s, reinterpret_cast<const T*>(qkv), B,
                      S, H, hd, pos0, lens, cs_tab, reinterpret_cast<T*>(q_out), reinterpret_cast<T*>(kc),
                      reinterpret_cast<T*>(vc), maxS, reinterpret_cast<T*>(q_keep));
+}
+void launch_rope_cache_slabs(const float* slab0, const float* slab1, int B, int S, int H, int hd, const int* pos0,
+                             const int* lens, const float* cs_tab, void* q_out, void* kc, void* vc, int maxS, void* q_keep,
+                             hipStream_t s) {
+  if (hd % 16 || (((uintptr_t)slab0 | (uintptr_t)slab1 | (uintptr_t)q_out | (uintptr_t)kc | (uintptr_t)vc | (uintptr_t)q_keep |
+                   (uintptr_t)cs_tab) & 15))
+    throw std::runtime_error("rope_cache_slabs: head dim % 16 and 16-byte aligned buffers");
+  hipLaunchKernelGGL(rope_cache_vec_kernel<true>, dim3(S, B), dim3(256), 0, s, (const bf16*)nullptr, slab0, slab1, S, H, hd,
+                     pos0, lens, cs_tab, reinterpret_cast<bf16*>(q_out), reinterpret_cast<bf16*>(kc),
+                     reinterpret_cast<bf16*>(vc), maxS, reinterpret_cast<bf16*>(q_keep));
 }
 template void launch_rope_cache<float>(const void*, int, int, int, int, const int*, const int*, const float*,
                                        void*, void*, void*, int, void*, hipStream_t);
