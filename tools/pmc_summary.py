@@ -26,6 +26,8 @@ TAGS = {  # bench.py roofline tag -> kernel-name prefix
     "gemm_bf16_64x256": "gemm_glds_kernel<64, 256, 1, 4, 2, false>",
     "gemm_bf16_64x256s3": "gemm_glds_kernel<64, 256, 1, 4, 3, false>",
     "gemm_bf16_128x160s3": "gemm_glds_kernel<128, 160, 4, 2, 3, false>",
+    "gemm_bf16_320x96": "gemm_glds_kernel<320, 96, 4, 2, 2, false>",
+    "gemm_bf16_320x64": "gemm_glds_kernel<320, 64, 4, 2, 3, false>",
     "gemm_bf16_128x128": "gemm_kernel<anyref::bf16, 128, 128, 64>",
     "gemm_bf16_64x128": "gemm_kernel<anyref::bf16, 64, 128, 64>",
     "gemm_bf16_64x64": "gemm_kernel<anyref::bf16, 64, 64, 64>",
@@ -33,6 +35,7 @@ TAGS = {  # bench.py roofline tag -> kernel-name prefix
     "attn_bf16_hd80_w8": "attn_kernel<anyref::bf16, 80, 8, 64, 0>",
     "attn_bf16_hd80_w13_res": "attn_kernel<anyref::bf16, 80, 13, 48, 5>",
     "attn_bf16_hd128": "attn_kernel<anyref::bf16, 128, 4, 0, 0>",
+    "attn_bf16_hd64_res": "attn_kernel<anyref::bf16, 64, 4, 64, 5>",
     "decode_attn_bf16": "decode_attn_kernel<anyref::bf16, 128>",
 }
 
