@@ -13,6 +13,8 @@
 #include <type_traits>
 
 #include "decode_attn.h"
+#include <mutex>
+
 #include "kernels.h"
 
 namespace anyref {
@@ -559,12 +561,19 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(AttnArgs a, int HD) {
 // per-stream partial-result workspace (grown on demand, like the split-K slabs in gemm.hip)
 namespace {
 struct AttnWs { hipStream_t s; float* p; size_t cap; };
+// process-wide, keyed by the stream handle (unique while the stream lives): a handle destroyed on another thread
+// (Python GC) still finds and frees the workspaces of the streams it owns.  Entries are only touched under the lock.
+std::mutex& attn_pool_mu() {
+  static std::mutex mu;
+  return mu;
+}
 std::vector<AttnWs>& attn_pool() {
-  static thread_local std::vector<AttnWs> pool;
+  static std::vector<AttnWs> pool;
   return pool;
 }
 }  // namespace
 void attn_release_workspace(hipStream_t s) {
+  std::lock_guard<std::mutex> lock(attn_pool_mu());
   auto& pool = attn_pool();
   for (size_t i = 0; i < pool.size(); ++i)
     if (pool[i].s == s) {
@@ -575,6 +584,7 @@ void attn_release_workspace(hipStream_t s) {
 }
 static float* attn_workspace(hipStream_t s, size_t bytes) {
   using Ws = AttnWs;
+  std::lock_guard<std::mutex> lock(attn_pool_mu());
   auto& pool = attn_pool();
   for (auto& w : pool)
     if (w.s == s) {

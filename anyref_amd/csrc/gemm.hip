@@ -15,6 +15,8 @@
 #include <type_traits>
 #include <utility>
 #include <vector>
+#include <mutex>
+
 #include "kernels.h"
 
 namespace anyref {
@@ -670,13 +672,20 @@ __global__ __launch_bounds__(NT) void splitk_reduce_norm_kernel(const float* __r
 // per-stream slab workspace (grown on demand; streams never share one)
 namespace {
 struct SplitKWs { hipStream_t s; float* p; size_t cap; };
+// process-wide, keyed by the stream handle (unique while the stream lives): a handle destroyed on another thread
+// (Python GC) still finds and frees the workspaces of the streams it owns.  Entries are only touched under the lock.
+std::mutex& splitk_pool_mu() {
+  static std::mutex mu;
+  return mu;
+}
 std::vector<SplitKWs>& splitk_pool() {
-  static thread_local std::vector<SplitKWs> pool;
+  static std::vector<SplitKWs> pool;
   return pool;
 }
 }  // namespace
 static float* splitk_workspace(hipStream_t s, size_t bytes) {
   using Ws = SplitKWs;
+  std::lock_guard<std::mutex> lock(splitk_pool_mu());
   auto& pool = splitk_pool();
   for (auto& w : pool)
     if (w.s == s) {
@@ -719,6 +728,7 @@ static const GemmKnobs& knobs() {
 // growing the workspace synchronises the stream)
 void gemm_reserve_workspace(hipStream_t s, size_t bytes) { (void)splitk_workspace(s, bytes); }
 void gemm_release_workspace(hipStream_t s) {
+  std::lock_guard<std::mutex> lock(splitk_pool_mu());
   auto& pool = splitk_pool();
   for (size_t i = 0; i < pool.size(); ++i)
     if (pool[i].s == s) {

@@ -143,6 +143,8 @@ class Model : public ModelBase {
     if (stage_) (void)hipHostFree(stage_);
     for (auto e : ev_tok_)
       if (e) (void)hipEventDestroy(e);
+    for (auto e : stage_ev_)
+      if (e) (void)hipEventDestroy(e);
   }
   const char* mode_name() const override { return sizeof(T) == 2 ? (fp8w_ ? "bf16+fp8w" : "bf16") : "f32"; }
   void finalize() override;
@@ -180,6 +182,7 @@ class Model : public ModelBase {
                      int rowpad = 0);
   LinF pack_linear_f32(const std::string& wname, const std::string& bname, int n, int k);
   Affine affine(const std::string& prefix, bool bias = true);
+  void resample_rel_pos(const std::string& name, int rows, int hd);
   template <typename U>
   U* talloc(size_t n) {
     return reinterpret_cast<U*>(dalloc(n * sizeof(U)));
@@ -357,9 +360,23 @@ class Model : public ModelBase {
   int64_t* next_host_ = nullptr;  // pinned, two slots of max_batch tokens (the greedy loop runs one step ahead)
   hipEvent_t ev_tok_[2] = {nullptr, nullptr};
   // pinned int staging for the small index vectors a call uploads (no host wait for a pageable copy to drain).
-  // One region per purpose; a region is rewritten only after a later stream sync of the same or the next call.
+  // One region per purpose, each with an event recorded behind its last queued copy: the host waits on that event
+  // before it rewrites the region (stage_begin), so a call that returns with copies still queued -- seg_tail and
+  // forward_teacher never sync, and run_tail's copies sit in front of a 10+ ms encoder -- cannot have them read the
+  // NEXT call's indices.  The wait is free whenever the copy has already run (always, in generate's loop).
   int* stage_ = nullptr;
   int *stage_first_ = nullptr, *stage_extra_ = nullptr, *stage_seg_ = nullptr, *stage_kl_ = nullptr;
+  enum { ST_FIRST = 0, ST_EXTRA, ST_SEG, ST_KL, ST_N };
+  hipEvent_t stage_ev_[ST_N] = {nullptr, nullptr, nullptr, nullptr};
+  bool stage_busy_[ST_N] = {false, false, false, false};
+  void stage_begin(int r) {
+    if (stage_busy_[r]) HIP_TRY(hipEventSynchronize(stage_ev_[r]));
+    stage_busy_[r] = false;
+  }
+  void stage_end(int r, hipStream_t s) {
+    HIP_TRY(hipEventRecord(stage_ev_[r], s));
+    stage_busy_[r] = true;
+  }
 
   // ---- ImageBind audio trunk (f-4; present iff cfg.aud_blocks > 0) ----
   struct AudBlock {
@@ -490,6 +507,33 @@ Affine Model<T>::affine(const std::string& prefix, bool bias) {
   a.g = own_f32(prefix + ".weight");
   if (bias) a.b = own_f32(prefix + ".bias");
   return a;
+}
+
+// get_rel_pos's table fix-up (image_encoder.py:333-345): a rel_pos table [L, hd] with L != 2*size-1 is resampled along
+// L with F.interpolate(mode="linear", align_corners=False) -- output row i at src = max((i + .5) * L / rows - .5, 0),
+// blending rows floor(src) and floor(src) + 1 (clamped) with (1 - frac, frac), in fp32 like ATen.  Input-independent,
+// so it is done on the host at finalize and the kernels only ever see (2*size-1)-row tables.
+template <typename T>
+void Model<T>::resample_rel_pos(const std::string& name, int rows, int hd) {
+  const RawTensor& t = raw(name);
+  if (t.shape.size() != 2 || t.shape[1] != hd || t.shape[0] < 1)
+    throw std::runtime_error("rel_pos table " + name + " is not [L, head_dim]");
+  const int L = (int)t.shape[0];
+  if (L == rows) return;
+  const std::vector<float> src = to_host(name);
+  std::vector<float> dst((size_t)rows * hd);
+  const float scale = (float)L / (float)rows;
+  for (int i = 0; i < rows; ++i) {
+    const float x = std::max(scale * ((float)i + 0.5f) - 0.5f, 0.f);
+    const int i0 = std::min((int)floorf(x), L - 1), i1 = std::min(i0 + 1, L - 1);
+    const float l1 = std::min(std::max(x - (float)i0, 0.f), 1.f), l0 = 1.f - l1;
+    for (int d = 0; d < hd; ++d) dst[(size_t)i * hd + d] = l0 * src[(size_t)i0 * hd + d] + l1 * src[(size_t)i1 * hd + d];
+  }
+  RawTensor r;
+  r.shape = {rows, hd};
+  r.p = upload_f32(dst);
+  dfree(raw_[name].p);
+  raw_[name] = r;
 }
 
 static const char* CLIP_P = "model.vision_tower.vision_tower.vision_model.";
@@ -657,6 +701,7 @@ void Model<T>::finalize() {
       stage_extra_ = stage_first_ + n_first;
       stage_seg_ = stage_extra_ + n_extra_max;
       stage_kl_ = stage_seg_ + n_seg;
+      for (auto& e : stage_ev_) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     if (c.rephrase_weight > 0.f) ensure_q_last();
   }
@@ -698,10 +743,9 @@ void Model<T>::finalize() {
       L.lin1 = pack_linear(bp + "mlp.lin1.weight", bp + "mlp.lin1.bias", c.sam_mlp_ratio * D, D);
       L.lin2 = pack_linear(bp + "mlp.lin2.weight", bp + "mlp.lin2.bias", D, c.sam_mlp_ratio * D);
       const int sz = L.global ? g : ws;
-      if (raw(bp + "attn.rel_pos_h").numel() != (int64_t)(2 * sz - 1) * hd)
-        throw std::runtime_error("rel_pos table of " + bp + " is not (2*size-1) x head_dim (interpolation unsupported)");
-      if (raw(bp + "attn.rel_pos_w").numel() != (int64_t)(2 * sz - 1) * hd)
-        throw std::runtime_error("rel_pos_w table of " + bp + " has the wrong shape");
+      // a table of another length (checkpoint trained at another window / image size) is resampled once, here
+      resample_rel_pos(bp + "attn.rel_pos_h", 2 * sz - 1, hd);
+      resample_rel_pos(bp + "attn.rel_pos_w", 2 * sz - 1, hd);
       const int Np = 2 * sz;
       // K padded with ZERO weights to a multiple of 64 (the fast GEMM's K tile): the A operand
       // then reads a few finite q/k values past this head's 80 columns, multiplied by zero.
@@ -1492,6 +1536,7 @@ int Model<T>::splice_inputs(hipStream_t s, const int64_t* input_ids, const int32
                       H, slen_dev_, s);
   if (n_extra > 0) {
     if (n_extra > (int)cfg.max_batch * std::max(cfg.max_seg, 64)) throw std::runtime_error("too many extra slots");
+    stage_begin(ST_EXTRA);
     int *eb = stage_extra_, *ep = stage_extra_ + n_extra;  // pinned: the copies below need no host wait
     for (int i = 0; i < n_extra; ++i) {
       const int b = extra_slots[2 * i], p = extra_slots[2 * i + 1];
@@ -1501,6 +1546,7 @@ int Model<T>::splice_inputs(hipStream_t s, const int64_t* input_ids, const int32
     }
     HIP_TRY(hipMemcpyAsync(idx_a_, eb, n_extra * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(idx_b_, ep, n_extra * 4, hipMemcpyHostToDevice, s));
+    stage_end(ST_EXTRA, s);
     launch_scatter_rows(extra_embeds, idx_a_, idx_b_, n_extra, l_x_, Sp, H, s);
   }
   return Sp;
@@ -1598,14 +1644,18 @@ void Model<T>::run_tail(hipStream_t s, const float* sam_images, int B, const std
   if (off > out_masks_cap) throw std::runtime_error("out_masks capacity too small");
   if (done > nseg) throw std::runtime_error("internal: more early [SEG] masks than [SEG] tokens");
   if (nseg == done) return;
+  stage_begin(ST_SEG);
   for (int i = 0; i < nseg; ++i) {
     stage_seg_[i] = seg_b[i];
     stage_seg_[nseg + i] = seg_pos[i];
   }
   HIP_TRY(hipMemcpyAsync(idx_a_, stage_seg_, nseg * 4, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(idx_b_, stage_seg_ + nseg, nseg * 4, hipMemcpyHostToDevice, s));
+  stage_end(ST_SEG, s);
   launch_gather_rows(hidden_all_, S, H, idx_a_, idx_b_, nseg, seg_h_, s);
   if (c.rephrase_weight > 0.f) {
+    stage_begin(ST_KL);
+    bool kl_used = false;
     // anyref.py:735-755,767-769: the first [SEG] of image i gets + w * sum_j attn_j * hidden_j
     const int nh = c.llm_heads, hd = H / nh;
     T* kc = kcache_ + cache_layer_stride_ * (c.llm_layers - 1);
@@ -1622,12 +1672,14 @@ void Model<T>::run_tail(hipStream_t s, const float* sam_images, int B, const std
       } else {
         stage_kl_[b] = e0 + 1;
         HIP_TRY(hipMemcpyAsync(kvlen_dev_ + b, stage_kl_ + b, 4, hipMemcpyHostToDevice, s));
+        kl_used = true;
         launch_attn_row_mean<T>(q_last_ + ((size_t)b * S + e0) * H, 0, hd, kc + (size_t)b * S * H, 0, H, hd,
                                 kvlen_dev_ + b, 1, nh, hd, 1.f / sqrtf((float)hd), attn_row_ + (size_t)b * S, S, s);
       }
       launch_rephrase(hidden_all_ + (size_t)b * S * H, H, attn_row_ + (size_t)b * S, s0, e0, c.rephrase_weight,
                       seg_h_ + (size_t)i * H, s);
     }
+    if (kl_used) stage_end(ST_KL, s);
   }
   gemmf(s, seg_h_, H, fc1_, seg_t_, H, nseg, ACT_RELU);
   gemmf(s, seg_t_, H, fc2_, pred_emb_, c.out_dim, nseg, ACT_NONE);
@@ -1683,6 +1735,7 @@ void Model<T>::generate(hipStream_t s, const float* clip_images, const float* sa
   fork_sam(s, sam_images, B);
   // first token: logits of the last prompt row of every sequence
   {
+    stage_begin(ST_FIRST);
     int *bb = stage_first_, *pp = stage_first_ + B, *sl = stage_first_ + 2 * B;
     for (int b = 0; b < B; ++b) {
       bb[b] = b;
@@ -1692,6 +1745,7 @@ void Model<T>::generate(hipStream_t s, const float* clip_images, const float* sa
     HIP_TRY(hipMemcpyAsync(idx_a_, bb, B * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(idx_b_, pp, B * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(pos_dev_, sl, B * 4, hipMemcpyHostToDevice, s));
+    stage_end(ST_FIRST, s);
     launch_gather_rows(hidden_all_, S, H, idx_a_, idx_b_, B, l_xlast_, s);
     GemvArgs h;
     h.x = l_xlast_; h.ldx = H; gemv_w(h, lm_head_); h.y = l_logits_; h.ldy = c.llm_vocab; h.B = B; h.N = c.llm_vocab;
@@ -1777,6 +1831,8 @@ void Model<T>::forward_teacher(hipStream_t s, const float* clip_images, const fl
   const int H = c.llm_dim, S = c.llm_max_seq, n_img = clip_n_;
   const bool keep_q = c.rephrase_weight > 0.f;
   sam_head_done_ = false;
+  early_done_ = 0;  // a generate() that threw between early_seg and run_tail must not leak its count into this call
+  early_stop_ = false;
   SamJoinGuard<Model<T>> join_guard{this, s};
   fork_sam(s, sam_images, B);
   clip_tower(s, clip_images, B);
@@ -1820,6 +1876,8 @@ void Model<T>::seg_tail(hipStream_t s, const float* sam_images, const int64_t* i
   const int H = c.llm_dim, S = c.llm_max_seq, shift = clip_n_ - 1;  // the reference's hard-coded "+255"
   if (hidden_rows <= 0 || hidden_rows > S) throw std::runtime_error("hidden_rows exceeds llm_max_seq");
   if (c.rephrase_weight > 0.f && !attn_mean) throw std::runtime_error("rephrase_weight > 0 needs attn_mean");
+  early_done_ = 0;  // see forward_teacher
+  early_stop_ = false;
   for (int b = 0; b < B; ++b)
     HIP_TRY(hipMemcpyAsync(hidden_all_ + (size_t)b * S * H, hidden + (size_t)b * hidden_rows * H,
                            (size_t)hidden_rows * H * 4, hipMemcpyDeviceToDevice, s));

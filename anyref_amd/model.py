@@ -379,8 +379,13 @@ class AnyRefForCausalLM:
         return out
 
     # ---- helpers ---------------------------------------------------------------------------
-    def _rows(self, input_ids: torch.Tensor, attention_masks: Optional[torch.Tensor]):
-        """-> (ids int64 host [B,Lmax] right-aligned rows, lens int32 [B])."""
+    def _rows(self, input_ids: torch.Tensor, attention_masks: Optional[torch.Tensor], keep_out: Optional[list] = None,
+              keep_in: Optional[list] = None):
+        """-> (ids int64 host [B,Lmax] right-aligned rows, lens int32 [B]).
+
+        `keep_out` receives the per-row index tensors that were kept; `keep_in` applies such a list instead of
+        deriving one (labels must be cut exactly where their `input_ids` row was: a label row holds -100 / ids and
+        never equals the pad id, so the pad rule below cannot be evaluated on it)."""
         ids = input_ids.detach().to("cpu", torch.long)
         if ids.dim() == 1:
             ids = ids[None]
@@ -389,15 +394,20 @@ class AnyRefForCausalLM:
         pad = self.config.pad_token_id
         for b in range(B):
             r = ids[b]
-            if attention_masks is not None:
-                r = r[attention_masks[b].to("cpu").bool()]
+            keep = torch.arange(Lm)
+            if keep_in is not None:
+                keep = keep_in[b]
+            elif attention_masks is not None:
+                keep = attention_masks[b].to("cpu").bool().nonzero().flatten()
             elif B > 1 and pad is not None:
                 # the callers' batched path passes left-padded ids and NO mask (eval_referseg.py:124-137); the
                 # collator's own mask is `input_ids.ne(pad_token_id)` (utils/coco_instance.py:142): strip the pad
                 # runs at both ends of the row (pad = unk never opens or closes a prompt: BOS ... "ASSISTANT:")
-                keep = (r != int(pad)).nonzero().flatten()
-                r = r[int(keep[0]): int(keep[-1]) + 1] if len(keep) else r[:1]
-            rows.append(r)
+                nz = (r != int(pad)).nonzero().flatten()
+                keep = torch.arange(int(nz[0]), int(nz[-1]) + 1) if len(nz) else torch.arange(1)
+            if keep_out is not None:
+                keep_out.append(keep)
+            rows.append(r[keep])
         lens = torch.tensor([len(r) for r in rows], dtype=torch.int32)
         out = torch.zeros(B, int(lens.max()), dtype=torch.long)
         for b, r in enumerate(rows):
@@ -626,8 +636,8 @@ class AnyRefForCausalLM:
                 o = int(offs[b])
                 pred_masks.append(out_masks[o: o + n * h * w].view(n, h, w))
             res = (output_ids, pred_masks, (None, None, None))
-        if self.success_arity == 2 and res[1] is not None and total >= B:
-            res = res[:2]                                 # the reference's own success path (anyref.py:822)
+        if self.success_arity == 2 and res[1] is not None and not (self.cfg.rephrase_weight > 0 and total < B):
+            res = res[:2]                                 # the reference's own success path (anyref.py:822): any [SEG], no `no_mask`
         if _return_extras:
             return res, dict(out_lens=out_lens, nseg=out_nseg, low_res=out_low, hidden=hid)
         return res
@@ -646,9 +656,10 @@ class AnyRefForCausalLM:
                           **kwargs):
         """Teacher-forced `model_forward_new` (anyref.py:239-466), inference arithmetic on the GPU,
         losses (`anyref.py:19-68,432-450`) evaluated with torch on the returned logits."""
-        ids, lens = self._rows(input_ids, attention_masks)
+        keeps: list = []
+        ids, lens = self._rows(input_ids, attention_masks, keep_out=keeps)
         B, Lmax = ids.shape
-        lab_rows, _ = self._rows(labels, attention_masks)
+        lab_rows, _ = self._rows(labels, None, keep_in=keeps)   # the same positions as the ids, whatever chose them
         clip = clip_images.to(self.device, torch.float32).contiguous()
         sam = sam_images.to(self.device, torch.float32).contiguous()
         extra, slots, n_extra = self._extra(ids, lens, audios, self._ref_features(ref_images, B))

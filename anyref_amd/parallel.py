@@ -84,12 +84,13 @@ class DataParallelAnyRef:
         pick = lambda x: None if x is None else x[sl]
         Lout = input_ids.shape[1] + max_new_tokens
         if hi > lo:
-            (ids, masks, rest), ex = m.generate(
+            res, ex = m.generate(
                 clip_images[sl], input_ids[sl], sam_images[sl], sam_resized_sizes[sl], height[sl], width[sl],
                 audios=pick(audios), ref_images=pick(ref_images), max_new_tokens=max_new_tokens,
                 attention_masks=pick(attention_masks), _return_extras="low")
             if self.world == 1:
-                return ids, masks, rest
+                return res
+            ids = res[0]                       # (ids, masks[, rest]): 2 or 3 values by `model.success_arity`
             low, nseg, lens = ex["low_res"], ex["nseg"].to(m.device), ex["out_lens"].to(m.device)
         else:
             # a global batch smaller than the world leaves this rank without images: it still takes part in both
@@ -103,11 +104,19 @@ class DataParallelAnyRef:
         idp[:, : ids.shape[1]] = ids
         low, nseg, gids, glen = gather_results(low, nseg, idp, lens, n, self.group)
         out_ids = gids[:, : int(glen.max())]
-        if int(nseg.sum()) == 0:
+        total = int(nseg.sum())
+        if total == 0:
             return out_ids, None, (None, None, None)
+        if m.cfg.rephrase_weight > 0 and total < n:
+            # anyref.py:739-744,763-765 on the GLOBAL batch (what a single process would have seen): fewer [SEG]
+            # tokens than samples with rephrasing on is the reference's `no_mask` return
+            z = torch.zeros((1, int(height[0]), int(width[0])), device=m.device, dtype=torch.float32)
+            return out_ids, [z] * n, (None, None, None)
         # full-resolution logits from the gathered low-res ones (per-mask bilinear, sam.py:137-172)
         pred = []
         for b in range(n):
             k = int(nseg[b])
             pred.append(m.postprocess(low[b, :k], sam_resized_sizes[b], (int(height[b]), int(width[b]))))
+        if getattr(m, "success_arity", 3) == 2:
+            return out_ids, pred               # the reference's own success path (anyref.py:822)
         return out_ids, pred, (None, None, None)

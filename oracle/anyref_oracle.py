@@ -264,10 +264,26 @@ def greedy_generate(w: W, cfg, embeds: torch.Tensor, max_new_tokens: int,
 # ----------------------------------------------------------------------------------------
 # SAM image encoder (image_encoder.py:17-426)
 # ----------------------------------------------------------------------------------------
+def resample_rel_pos(rel_pos: torch.Tensor, length: int) -> torch.Tensor:
+    """The table-length fix-up of get_rel_pos (image_encoder.py:333-345): a table [L, C] whose L is not the
+    2*size-1 the block needs is resampled along L by `F.interpolate(mode="linear")` (align_corners=False): output
+    row i sits at src = max((i + 0.5) * L / length - 0.5, 0) and blends rows floor(src) and floor(src) + 1
+    (clamped to L - 1) with weights (1 - frac, frac), all in fp32."""
+    L = rel_pos.shape[0]
+    if L == length:
+        return rel_pos
+    scale = torch.tensor(L, dtype=torch.float32) / length
+    src = (scale * (torch.arange(length, dtype=torch.float32) + 0.5) - 0.5).clamp_min(0.0)
+    i0 = src.floor().long().clamp_max(L - 1)
+    i1 = (i0 + 1).clamp_max(L - 1)
+    lam = (src - i0.float()).clamp(0.0, 1.0)[:, None]
+    return (1.0 - lam) * rel_pos[i0] + lam * rel_pos[i1]
+
+
 def _rel_pos_table(rel_pos: torch.Tensor, size: int) -> torch.Tensor:
-    """get_rel_pos (image_encoder.py:321-351) for q_size == k_size == size and a table of
-    exactly 2*size-1 rows (what every SAM checkpoint has): R[q, k] = rel_pos[q - k + size - 1]."""
-    assert rel_pos.shape[0] == 2 * size - 1, "rel_pos interpolation is not part of the hot path"
+    """get_rel_pos (image_encoder.py:321-351) for q_size == k_size == size: R[q, k] = rel_pos[q - k + size - 1],
+    on the table resampled to 2*size-1 rows when the checkpoint's has another length."""
+    rel_pos = resample_rel_pos(rel_pos, 2 * size - 1)
     idx = torch.arange(size)[:, None] - torch.arange(size)[None, :] + (size - 1)
     return rel_pos[idx]                                                # [size, size, hd]
 

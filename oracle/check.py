@@ -18,9 +18,10 @@ import torch
 
 
 def compare_generate(model, ref: Dict, clip, ids_row: torch.Tensor, sam, sizes, H, W, max_new_tokens: int,
-                     lm_head: Optional[torch.Tensor] = None, n_img: int = 256) -> Dict:
-    """One image.  `ref` = `anyref_oracle.anyref_generate(...)` of the same inputs; `model` = the HIP backend."""
-    out_ids, masks, _ = model.generate(clip, ids_row[None], sam, sizes, H, W, max_new_tokens=max_new_tokens)
+                     lm_head: Optional[torch.Tensor] = None, n_img: int = 256, **gen_kw) -> Dict:
+    """One image.  `ref` = `anyref_oracle.anyref_generate(...)` of the same inputs; `model` = the HIP backend.
+    `gen_kw` (e.g. `audios=[mel]`) goes to `generate` and to the teacher-forced `model_forward_new` alike."""
+    out_ids, masks, _ = model.generate(clip, ids_row[None], sam, sizes, H, W, max_new_tokens=max_new_tokens, **gen_kw)
     torch.cuda.synchronize()
     got = out_ids[0].cpu().tolist()
     want = ref["output_ids"][0].tolist()
@@ -41,7 +42,7 @@ def compare_generate(model, ref: Dict, clip, ids_row: torch.Tensor, sam, sizes, 
         if ref_mask is not None:
             full = ref["output_ids"][0]
             fw = model.model_forward_new(clip, sam, full[None], full[None].clone(), None, sizes, None, H, W,
-                                         _return_extras=True)
+                                         _return_extras=True, **gen_kw)
             torch.cuda.synchronize()
             masks = fw.get("pred_masks")
             res["teacher_forced"] = True

@@ -160,6 +160,56 @@ def make_sam_h_width(seed=11):
     print("sam_h_width: emb", tuple(emb.shape), "absmax", float(emb.abs().max()))
 
 
+def relpos_interp_tables(cfg, seed):
+    """rel_pos tables of OTHER lengths than 2*size-1 for every block of `sam_w14`'s encoder (a checkpoint trained
+    at another window / image size): block 0 (14-window) gets 13-row tables (up-sampled to 27), block 1 (global,
+    grid 14) 39-row tables (down-sampled to 27) -- both directions of image_encoder.py:335-345."""
+    g = torch.Generator().manual_seed(seed + 5)
+    hd = cfg.sam.dim // cfg.sam.heads
+    pre = SAM_PREFIX + "image_encoder.blocks."
+    return {pre + "0.attn.rel_pos_h": torch.randn(13, hd, generator=g) * 0.3,
+            pre + "0.attn.rel_pos_w": torch.randn(13, hd, generator=g) * 0.3,
+            pre + "1.attn.rel_pos_h": torch.randn(39, hd, generator=g) * 0.3,
+            pre + "1.attn.rel_pos_w": torch.randn(39, hd, generator=g) * 0.3}
+
+
+def make_sam_relpos_interp(seed=11):
+    """`get_rel_pos` with a mismatched table (image_encoder.py:333-345): the reference's encoder with its rel_pos
+    parameters replaced by tables of other lengths; stores the encoder output and the reference's resampled tables."""
+    sys.path.insert(0, REF_SAM)
+    import modeling as ref
+    from modeling import image_encoder as ref_ie
+    from functools import partial
+    cfg = golden_cfgs()["sam_w14"]
+    s = cfg.sam
+    sd = synth_state_dict(cfg, seed=seed, scale=0.05)
+    enc = ref.ImageEncoderViT(
+        depth=s.depth, embed_dim=s.dim, img_size=s.img_size, mlp_ratio=s.mlp_ratio,
+        norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), num_heads=s.heads, patch_size=s.patch,
+        qkv_bias=True, use_rel_pos=True, global_attn_indexes=list(s.global_idx),
+        window_size=s.window, out_chans=s.out_chans).eval()
+    pre = SAM_PREFIX + "image_encoder."
+    enc.load_state_dict({k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}, strict=True)
+    tabs = relpos_interp_tables(cfg, seed)
+    for k, v in tabs.items():
+        blk, name = int(k.split("blocks.")[1].split(".")[0]), k.rsplit(".", 1)[1]
+        setattr(enc.blocks[blk].attn, name, torch.nn.Parameter(v.clone()))
+    img, _ = golden_inputs(cfg, seed)
+    with torch.no_grad():
+        emb = enc(img)
+        # the resampled 27-row table as the reference's get_rel_pos sees it: R[q, k] = table[q - k + 13], so
+        # R[0, 13..0] are rows 0..13 and R[1..13, 0] rows 14..26
+        res_full = {}
+        for k, v in tabs.items():
+            R = ref_ie.get_rel_pos(14, 14, v)
+            res_full[k] = torch.cat([R[0].flip(0), R[1:, 0]], 0)
+    np.savez_compressed(os.path.join(HERE, "sam_relpos_interp.npz"), seed=seed, wsum=checksum(sd, pre),
+                        insum=np.float64(img.double().abs().sum()), emb=emb.numpy()[:, ::2],
+                        **{"tab_" + k.split("blocks.")[1]: v.numpy() for k, v in tabs.items()},
+                        **{"res_" + k.split("blocks.")[1]: v.numpy() for k, v in res_full.items()})
+    print("sam_relpos_interp: emb", tuple(emb.shape), "resampled", tuple(next(iter(res_full.values())).shape))
+
+
 def make_llm_clip(seed=7):
     from transformers import LlamaConfig, LlamaForCausalLM, CLIPVisionConfig, CLIPVisionModel
     cfg = llm_clip_cfg()
@@ -209,3 +259,4 @@ if __name__ == "__main__":
         make_sam(name, cfg, seed=11 + i)
     make_llm_clip()
     make_sam_h_width()
+    make_sam_relpos_interp()

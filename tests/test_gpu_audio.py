@@ -83,3 +83,55 @@ def test_generate_with_raw_mel_through_the_hip_trunk():
     n = ref["hidden"][0].shape[0]
     assert (ex["hidden"][0, :n].cpu() - ref["hidden"][0]).abs().max().item() < 2e-4
     assert (masks[0].cpu() - ref["pred_masks"][0]).abs().max().item() <= 1e-3
+
+
+@pytest.mark.parametrize("mode", ["parity", "perf"])
+def test_c4_full_width_raw_mel_through_the_hip_trunk_vs_oracle(mode):
+    """BASELINE configs[3] at FULL WIDTH, reduced depth: 1024^2 SAM-H-width encoder (1280 wide, 16 heads of 80, one
+    14-window + one global block), CLIP ViT-L width (3 layers), two LLaMA-7B-width decoder layers, and the ImageBind
+    audio trunk at its REAL size (768 / 12 blocks / 12 heads, 3 clips of 128 x 204 mel) inside the handle: raw mel
+    clips -> HIP trunk -> audio_projector -> 3 <audio_ref> slots of an AVSBench-style prompt (utils/avsbench.py:256-259,
+    anyref.py:663-679) -> greedy decode -> [SEG] -> masks, against the CPU oracle fed by the PyTorch restatement of
+    the trunk (itself pinned to the reference's `get_audio_feature`, test above)."""
+    import dataclasses
+    from anyref_amd.audio import ImageBindAudio
+    from anyref_amd.config import ClipConfig, LlmConfig, SamConfig
+    from anyref_amd.model import AnyRefForCausalLM
+    from oracle.check import compare_generate
+    cfg = config_tiny()
+    cfg = dataclasses.replace(
+        cfg, clip=ClipConfig(image_size=224, patch=14, dim=1024, heads=16, layers=3, mlp=4096),
+        llm=LlmConfig(vocab=1000, dim=4096, heads=32, layers=2, mlp=11008, max_seq=512),
+        sam=SamConfig(img_size=1024, patch=16, dim=1280, depth=2, heads=16, window=14, global_idx=(1,)))
+    cfg.audio_trunk = AudioTrunkConfig()
+    sd = synth_state_dict(cfg, seed=51, init="fan_in")
+    trunk = ImageBindAudio().eval()
+    pre = "model.audio_encoder."
+    trunk.load_state_dict({k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}, strict=True)
+    g = torch.Generator().manual_seed(52)
+    clip = torch.randn(1, 3, 224, 224, generator=g)
+    sam = torch.randn(1, 3, 1024, 1024, generator=g)
+    body = torch.randint(3, 980, (60,), generator=g)
+    ids = torch.cat([torch.tensor([1, IMAGE_TOKEN_INDEX]), body[:3], torch.full((3,), AUDIO_REF_INDEX), body[3:]])   # L = 65
+    mel = torch.randn(1, 3, 1, 128, 204, generator=g)
+    with torch.no_grad():
+        _, emb = trunk.get_audio_feature(mel)
+    sizes, H, W = [(1024, 1024)], [1024], [1024]
+    T = 6
+    with torch.no_grad():
+        r0 = O.anyref_generate(sd, cfg, clip, [ids], sam, sizes, H, W, audio_embeds=[emb[0]], max_new_tokens=4, eos=False)
+        cfg.seg_token_idx = int(r0["output_ids"][0][-2])
+        ref = O.anyref_generate(sd, cfg, clip, [ids], sam, sizes, H, W, audio_embeds=[emb[0]], max_new_tokens=T, eos=False)
+    assert ref["pred_masks"] is not None
+    m = AnyRefForCausalLM.from_state_dict(cfg, {k: v.cuda() for k, v in sd.items()}, mode=mode, max_batch=1, max_seg=8)
+    m.config.eos_token_id = None
+    e_trunk = (m.audio_encode(mel).cpu() - emb[0]).abs().max().item()
+    r = compare_generate(m, ref, clip, ids, sam, sizes, H, W, T, sd["lm_head.weight"], cfg.clip.n_patches, audios=[mel])
+    print(f"C4_FULL_WIDTH[{mode}] trunk max-abs-err {e_trunk:.3e} (|emb| = 20) " +
+          " ".join(f"{k}={v:.3e}" if isinstance(v, float) else f"{k}={v}" for k, v in r.items()))
+    assert e_trunk <= TOL[mode]
+    if mode == "parity":
+        assert r["greedy_ids_identical"], r
+        assert r["mask_logit_max_abs_err"] <= 1e-3, r
+    else:
+        assert r["mask_logit_rel_err"] <= 0.009, r          # = test_gpu_e2e.PERF_MASK_REL

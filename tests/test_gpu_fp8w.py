@@ -91,6 +91,113 @@ def test_gemm_fp8_operand_vs_torch(M, N, K):
     assert err < 2e-3 * max(1.0, ref.abs().max().item()), err
 
 
+# ---- BASELINE configs[4] widths (13B: H = 5120, 40 heads of 128, MLP 13824): the shapes `bench.py --config c5` runs ----
+@pytest.mark.parametrize("B", [1, 4])
+@pytest.mark.parametrize("N,K,dual", [(15360, 5120, False),     # fused q/k/v projection (24 x-values per thread)
+                                      (5120, 13824, False),    # down_proj (K = 13824: the 32-value staging)
+                                      (13824, 5120, True),     # gate/up as 27648 interleaved rows -> SwiGLU pairs
+                                      (5120, 5120, False)])    # o_proj
+def test_gemv_fp8_13b_widths_vs_torch(B, N, K, dual):
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(B + N + K)
+    w = torch.randn(N, K, generator=g) * 0.02
+    w2 = torch.randn(N, K, generator=g) * 0.02
+    x = torch.randn(B, K, generator=g)
+    gain = torch.rand(K, generator=g) + 0.5
+    q, s = quantize_rows_fp8(w)
+    q2, s2 = quantize_rows_fp8(w2)
+    xn = x * torch.rsqrt((x * x).mean(-1, keepdim=True) + 1e-6) * gain
+    xb = xn.bfloat16().double()
+    ref = xb @ dequantize_rows_fp8(q, s).double().T
+    if dual:
+        ref = torch.nn.functional.silu(ref) * (xb @ dequantize_rows_fp8(q2, s2).double().T)
+    y = torch.empty(B, N, device="cuda")
+    keep = [x.cuda(), gain.cuda(), q.cuda(), q2.cuda(), s.cuda(), s2.cuda()]
+    rc = lib.anyref_op_gemv_fp8(None, P(keep[0]), P(keep[1]), 1e-6, P(keep[2]), P(keep[3]) if dual else None, P(keep[4]),
+                                P(keep[5]) if dual else None, P(y), None, B, N, K)
+    assert rc == 0, lib.anyref_op_last_error()
+    torch.cuda.synchronize()
+    err = (y.cpu().double() - ref).abs().max().item()
+    print(f"fp8 GEMV B={B} N={N} K={K} dual={dual}: max-abs-err {err:.3e} (scale {ref.abs().max().item():.2f})")
+    assert err < 2e-4 * max(1.0, ref.abs().max().item()), err
+
+
+@pytest.mark.parametrize("M", [320, 2560])                      # one prompt; batch 8 x S = 320 (configs[4])
+@pytest.mark.parametrize("N,K", [(15360, 5120), (5120, 13824), (5120, 5120)])
+def test_gemm_fp8_operand_13b_widths_vs_torch(M, N, K):
+    """fp8-operand MFMA GEMM at the 13B shapes: whole-M / 64 x 256 / 256^2 tiles, split-K with the row scale applied
+    in the reduction (M = 320, K >= 2048), the scale in the epilogue otherwise.  Reference: fp32 matmul of the same
+    bf16 activations with the DEQUANTISED weights (torch on the GPU; fp64 spot-check of a row block on the host)."""
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).bfloat16()
+    w = torch.randn(N, K, generator=g) * 0.02
+    resid = torch.randn(M, N, generator=g)
+    q, s = quantize_rows_fp8(w)
+    wd = dequantize_rows_fp8(q, s)
+    keep = [A.cuda(), q.cuda(), s.cuda(), resid.cuda()]
+    ref = keep[0].float() @ wd.cuda().T + keep[3]
+    C32 = torch.empty(M, N, device="cuda")
+    rc = lib.anyref_op_gemm_fp8(None, P(keep[0]), P(keep[1]), P(keep[2]), None, P(C32), P(keep[3]), M, N, K, 0, 1)
+    assert rc == 0, lib.anyref_op_last_error()
+    torch.cuda.synchronize()
+    scale = max(1.0, ref.abs().max().item())
+    err = (C32 - ref).abs().max().item()
+    ref64 = A[:16].double() @ wd.double().T + resid[:16].double()
+    err64 = (C32[:16].cpu().double() - ref64).abs().max().item()
+    print(f"fp8 GEMM M={M} N={N} K={K}: max-abs-err {err:.3e} vs torch fp32, {err64:.3e} vs fp64 rows (scale {scale:.2f})")
+    assert err < 2e-3 * scale and err64 < 2e-3 * scale, (err, err64)
+
+
+def test_generate_13b_shaped_layers_fp8w_batch8_vs_oracle():
+    """BASELINE configs[4] at reduced depth: two decoder layers at LLaMA-13B's real widths (5120 / 40 heads of 128 / MLP
+    13824; vocab 1000) behind the tiny vision towers, `perf_fp8w`, batch 8 -- the fp8-operand prefill GEMMs at M = 8 x S
+    rows, the MFMA decode path (B > 4: fp8 weights through the GEMM, split-K + scale in the reduction) and the padded
+    fp8 row stride -- every hidden state held against the CPU fp32 oracle on the DEQUANTISED weights.  Clone of
+    `test_generate_llama7b_shaped_layers_vs_oracle` (anyref.py:663-679 / :704-716 call sites)."""
+    import dataclasses
+    from anyref_amd.config import LlmConfig
+    from anyref_amd.model import AnyRefForCausalLM
+    from test_gpu_e2e import pad, PERF_HIDDEN_REL_7B
+    B = 8
+    cfg = config_tiny()
+    cfg = dataclasses.replace(cfg, llm=LlmConfig(vocab=1000, dim=5120, heads=40, layers=2, mlp=13824, max_seq=512))
+    sd = synth_state_dict(cfg, seed=31, scale=0.02)
+    sd_dq = dequantized_state_dict(sd)
+    clip, sam, ids = make_inputs(cfg, B, seed=32, L=65)
+    sizes, H, W = [(224, 224)] * B, [224] * B, [224] * B
+    rig_seg(cfg, sd_dq, clip, sam, ids, sizes, (H, W))
+    n_ref = 2
+    with torch.no_grad():
+        ref = O.anyref_generate(sd_dq, cfg, clip[:n_ref], ids[:n_ref], sam[:n_ref], sizes[:n_ref], H[:n_ref], W[:n_ref],
+                                max_new_tokens=6, eos=False)
+    m = AnyRefForCausalLM.from_state_dict(cfg, {k: v.cuda() for k, v in sd.items()}, mode="perf_fp8w", max_batch=B, max_seg=4)
+    m.config.eos_token_id = None
+    padded, mask = pad(ids)
+    (out_ids, masks, _), ex = m.generate(clip, padded, sam, sizes, H, W, max_new_tokens=6, attention_masks=mask,
+                                         _return_extras=True)
+    # B = 1 on the same handle: the fp8 decode GEMVs over the padded rows (K = 5120: 24 values / thread, K = 13824: 32)
+    (out1, _, _), ex1 = m.generate(clip[:1], ids[0][None], sam[:1], sizes[:1], H[:1], W[:1], max_new_tokens=6,
+                                   _return_extras=True)
+    for b in range(n_ref):
+        want_ids = ref["output_ids"][b]
+        n = ref["hidden"][b].shape[0]
+        Sp = len(ids[b]) + 255
+        want = ref["hidden"][b]
+        scale = want.abs().max().item()
+        runs = [("B=8", out_ids[b], ex["hidden"][b])] + ([("B=1", out1[0], ex1["hidden"][0])] if b == 0 else [])
+        for tag, oi, hid in runs:
+            same = oi[: len(want_ids)].cpu().tolist() == want_ids.tolist()
+            got = hid[:n].cpu()
+            perr = (got[:Sp] - want[:Sp]).abs().max().item()
+            print(f"[perf_fp8w 13B-shaped {tag}] row {b}: prefill hidden max-abs-err {perr:.3e} (scale {scale:.2f}), ids identical: {same}")
+            assert perr < PERF_HIDDEN_REL_7B * max(1.0, scale), f"prefill hidden err {perr} (scale {scale})"
+            if same:
+                derr = (got[Sp:] - want[Sp:]).abs().max().item()
+                print(f"[perf_fp8w 13B-shaped {tag}] row {b}: decode hidden max-abs-err {derr:.3e}")
+                assert derr < PERF_HIDDEN_REL_7B * max(1.0, scale), f"decode hidden err {derr} (scale {scale})"
+
+
 def test_generate_fp8w_matches_oracle_on_dequantised_weights():
     from anyref_amd.model import AnyRefForCausalLM
     cfg = config_tiny()

@@ -148,3 +148,23 @@ def test_clip_l_shaped_tower_vs_oracle(mode):
     _, clip2 = m.encode_images(images2, return_clip=True)
     e2 = close(clip2, ref2, TOL[mode], "CLIP-L-shaped tower, two images")
     print(f"[{mode}] CLIP-L-width tower max-abs-err vs oracle: {e1:.3e} (1 image), {e2:.3e} (2 images); range {ref.abs().max().item():.2f}")
+
+
+@pytest.mark.parametrize("mode", ["parity", "perf"])
+def test_rel_pos_interpolation_vs_reference(mode):
+    """`get_rel_pos` with rel_pos tables of another length than 2*size-1 (image_encoder.py:333-345: `F.interpolate(...,
+    mode="linear")`): the handle resamples them once at `finalize`; encoder output against the oracle and against what
+    the reference's own `ImageEncoderViT` produced with the same mismatched tables (13 -> 27 rows on the windowed block,
+    39 -> 27 on the global one; tests/golden/sam_relpos_interp.npz)."""
+    cfg = mg.golden_cfgs()["sam_w14"]
+    fx = np.load(os.path.join(HERE, "golden", "sam_relpos_interp.npz"))
+    seed = int(fx["seed"])
+    sd = synth_state_dict(cfg, seed=seed, scale=0.05)
+    sd.update(mg.relpos_interp_tables(cfg, seed))
+    img, _ = mg.golden_inputs(cfg, seed)
+    with torch.no_grad():
+        emb_ref = O.sam_image_encoder(sd, cfg, img)
+    m = build(cfg, sd, mode, max_batch=2, max_seg=2)
+    emb = m.sam_encode(img)
+    close(emb, emb_ref, TOL[mode], "encoder with resampled rel_pos tables vs oracle")
+    close(emb[:, ::2], fx["emb"], TOL[mode], "encoder with resampled rel_pos tables vs reference golden")

@@ -222,3 +222,22 @@ def test_sam_h_width_encoder_against_reference():
     with torch.no_grad():
         emb = O.sam_image_encoder(w, cfg, img)
     _close(emb[:, ::4, ::2, ::2], fx["emb"], 3e-5)
+
+
+def test_rel_pos_interpolation_against_reference():
+    """`get_rel_pos` with tables of another length (image_encoder.py:333-345): the oracle's resample against the
+    tables the reference's own function gathered from, and the encoder output of the reference run with them."""
+    cfg = mg.golden_cfgs()["sam_w14"]
+    fx = np.load(os.path.join(HERE, "golden", "sam_relpos_interp.npz"))
+    seed = int(fx["seed"])
+    w = synth_state_dict(cfg, seed=seed, scale=0.05)
+    assert abs(mg.checksum(w, SAM_PREFIX + "image_encoder.") - fx["wsum"]) < 1e-6 * fx["wsum"], "seeded weights drifted"
+    tabs = mg.relpos_interp_tables(cfg, seed)
+    for k, v in tabs.items():
+        short = k.split("blocks.")[1]
+        np.testing.assert_array_equal(v.numpy(), fx["tab_" + short])
+        _close(O.resample_rel_pos(v, 27), fx["res_" + short], 1e-6)
+    w.update(tabs)
+    img, _ = mg.golden_inputs(cfg, seed)
+    with torch.no_grad():
+        _close(O.sam_image_encoder(w, cfg, img)[:, ::2], fx["emb"])
