@@ -10,6 +10,7 @@ using namespace anyref;
 struct anyref_handle {
   std::unique_ptr<ModelBase> m;
   std::string err;
+  std::vector<StampRow> stamp_rows;  // last anyref_stamps_collect()
 };
 
 static thread_local std::string g_create_err;
@@ -18,9 +19,9 @@ static thread_local std::string g_create_err;
   if (!(h) || !(h)->m) return 1;               \
   try {                                        \
     struct ProfInstall {                       \
-      ProfInstall(Profiler* p) { g_prof = p; } \
-      ~ProfInstall() { g_prof = nullptr; }     \
-    } _pi(&(h)->m->prof);                      \
+      ProfInstall(Profiler* p, Stamper* t) { g_prof = p; g_stamp = t; } \
+      ~ProfInstall() { g_prof = nullptr; g_stamp = nullptr; }            \
+    } _pi(&(h)->m->prof, &(h)->m->stamp);      \
     body;                                      \
     hipError_t _e = hipGetLastError();         \
     if (_e != hipSuccess) {                    \
@@ -166,6 +167,27 @@ int anyref_profile_read(anyref_handle* h, int idx, char* name, int cap, double* 
   *count = st[idx].second.count;
   *flops = st[idx].second.flops;
   *bytes = st[idx].second.bytes;
+  return 0;
+}
+
+int anyref_stamps_enable(anyref_handle* h, int on) { GUARD(h, h->m->stamp.enable(on != 0)); }
+
+int anyref_stamps_collect(anyref_handle* h, int64_t* count) {
+  GUARD(h, {
+    h->stamp_rows = h->m->stamp.collect();
+    if (count) *count = (int64_t)h->stamp_rows.size();
+  });
+}
+
+int anyref_stamps_read(anyref_handle* h, int64_t idx, char* name, int cap, double* t0_us, double* t1_us, double* bytes,
+                       int* epoch) {
+  if (!h || idx < 0 || idx >= (int64_t)h->stamp_rows.size()) return -1;
+  const StampRow& r = h->stamp_rows[(size_t)idx];
+  snprintf(name, cap, "%s", r.tag.c_str());
+  *t0_us = r.t0_us;
+  *t1_us = r.t1_us;
+  *bytes = r.bytes;
+  if (epoch) *epoch = r.epoch;
   return 0;
 }
 

@@ -1004,6 +1004,18 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int b0, int nb) {
   __shared__ float red[NB][8];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int K = a.K;
+  // kernel-side timestamps (kernels.h: StampArgs): off in production (one uniform branch)
+  __shared__ unsigned long long st_t[2];
+  __shared__ unsigned st_cnt;
+  unsigned long long t_begin = 0;
+  if (a.stamp.base) {
+    t_begin = wall_clock64();
+    if (tid == 0) {
+      st_t[0] = ~0ull;
+      st_t[1] = 0;
+      st_cnt = 0;
+    }
+  }
 
   const WT* __restrict__ W = reinterpret_cast<const WT*>(a.W);
   const WT* __restrict__ W2 = reinterpret_cast<const WT*>(a.W2);
@@ -1196,10 +1208,25 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int b0, int nb) {
         for (int r = 0; r < RW; ++r) wcur[u][r] = wnxt[u][r];
     }
   }
+  if (a.stamp.base && lane == 0) {
+    // every wave folds its span into the workgroup's (LDS atomics; the init is ordered by the barrier after the x
+    // stage); the wave whose count comes back last has seen all of them and writes the workgroup's slot
+    atomicMin(&st_t[0], t_begin);
+    atomicMax(&st_t[1], (unsigned long long)wall_clock64());
+    if (atomicAdd(&st_cnt, 1u) == 7u) {
+      const int e = *a.stamp.epoch;
+      if (e < a.stamp.max_epoch) {
+        unsigned long long* p = a.stamp.base + (size_t)e * a.stamp.stride + (size_t)blockIdx.x * 2;
+        p[0] = st_t[0];
+        p[1] = st_t[1];
+      }
+    }
+  }
 }
 
 template <typename T, int NB>
-static void gemv_dispatch(const GemvArgs& a, int b0, int nb, hipStream_t s) {
+static void gemv_dispatch(const GemvArgs& a_in, int b0, int nb, hipStream_t s) {
+  GemvArgs a = a_in;
   const size_t lds = (size_t)NB * a.K * sizeof(T);
   if (lds > 150 * 1024) throw std::runtime_error("gemv: K too large for the LDS activation stage");
   // one or two 8-wave workgroups per CU depending on the LDS the activation stage needs
@@ -1224,6 +1251,7 @@ static void gemv_dispatch(const GemvArgs& a, int b0, int nb, hipStream_t s) {
     snprintf(tag, sizeof(tag), "gemv_%s%s_x%d", a.w_fp8 ? "fp8w" : (sizeof(T) == 2 ? "bf16" : "f32"),
              a.W2 ? "_swiglu" : "", XPT);
     ProfScope prof(tag, 2.0 * nb * a.N * (double)a.K * (a.W2 ? 2 : 1), wbytes, s);
+    if (g_stamp && g_stamp->on) a.stamp = g_stamp->slot(tag, wbytes, grid);
     if constexpr (sizeof(T) == 2) {
       if (a.w_fp8) {
         static bool attr8 = false;

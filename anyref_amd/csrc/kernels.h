@@ -3,6 +3,7 @@
 // `bf16` (perf mode, MFMA 16x16x32 bf16).  Accumulation and the residual stream are fp32 in both.
 #pragma once
 #include <cstdlib>
+#include <map>
 #include <string>
 #include <utility>
 #include <vector>
@@ -52,6 +53,51 @@ class Profiler {
   std::vector<int64_t> seen_;
 };
 extern thread_local Profiler* g_prof;
+
+// ---- kernel-side timestamps (bench.py's in-situ roofline) -----------------------------------------
+// hipEvent brackets cannot be placed inside a replayed hipGraph and rocprofv3 serialises the two streams of a call,
+// so neither sees a decode GEMV as it runs in production (graph replay, SAM encoder co-running).  With stamps on,
+// a stamping kernel records the 100 MHz wall clock itself: every workgroup writes {earliest wave start, latest wave
+// end} into its own 16-byte slot (plain stores, no global atomics); the host reduces a launch's slots to min / max.
+// A launch inside a captured step cannot get a fresh slot per replay (its arguments are baked in), so slots are
+// addressed as base + *epoch * stride: the captured step ends with a one-thread kernel that bumps *epoch.
+struct StampArgs {
+  unsigned long long* base = nullptr;  // null: the kernel does not stamp
+  const int* epoch = nullptr;          // device int (a constant 0 for eager launches)
+  unsigned stride = 0;                 // u64 elements per epoch
+  int max_epoch = 0;                   // replays past this are not recorded
+};
+struct StampRow {
+  std::string tag;
+  double bytes = 0;
+  double t0_us = 0, t1_us = 0;  // relative to the first stamp collected
+  int epoch = -1;               // replay index of the captured step, -1: eager launch
+};
+class Stamper {
+ public:
+  ~Stamper();
+  void enable(bool on);  // allocates / frees the device buffers
+  bool on = false;
+  // next slot for a launch of `grid` workgroups (called by a stamping launcher)
+  StampArgs slot(const char* tag, double bytes, int grid);
+  void graph_begin(int key);          // the launches up to graph_end() are being captured under `key`
+  void graph_end(hipStream_t cap);    // appends the epoch bump to the captured stream
+  bool graph_known(int key) const { return graphs_.count(key) != 0; }
+  void graph_replayed(int key) { epoch_keys_.push_back(key); }
+  std::vector<StampRow> collect();    // after the device has been synchronised; also resets the counters
+ private:
+  struct Rec { std::string tag; double bytes; int grid; size_t off; };
+  unsigned long long* buf_ = nullptr;
+  int* ctl_ = nullptr;  // [0] = epoch, [1] = constant 0
+  size_t eager_cap_ = 0, eager_used_ = 0, graph_off_ = 0, graph_stride_ = 0;
+  int max_epoch_ = 0;
+  int capturing_ = -1;
+  size_t cap_used_ = 0;
+  std::vector<Rec> eager_;
+  std::map<int, std::vector<Rec>> graphs_;
+  std::vector<int> epoch_keys_;
+};
+extern thread_local Stamper* g_stamp;
 struct ProfScope {  // RAII bracket used inside the launchers
   hipStream_t s;
   bool active;
@@ -132,6 +178,7 @@ struct GemvArgs {
   float* xn_out = nullptr;
   const int* xn_row_map = nullptr;
   int xn_ld = 0;
+  StampArgs stamp;  // filled by the launcher when kernel-side timestamps are on
 };
 template <typename T>
 void launch_gemv(const GemvArgs& a, hipStream_t s);

@@ -71,6 +71,7 @@ class ModelBase {
   void set_graphs(bool on) { use_graphs_ = on; }
   bool early_off_ = getenv("ANYREF_NO_EARLY_TAIL") != nullptr;
   Profiler prof;
+  Stamper stamp;  // kernel-side timestamps of the decode GEMVs (bench.py's in-situ roofline)
   std::string err;
   int n_unknown = 0;
 

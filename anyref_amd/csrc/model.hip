@@ -1011,7 +1011,9 @@ void Model<T>::decode_step_graph(hipStream_t s, int B, bool keep_q) {
     llm_decode_step(s, B, keep_q);
     return;
   }
-  const int key = B * 2 + (keep_q ? 1 : 0);
+  // with kernel-side timestamps on, the step is a graph of its own: its GEMVs carry their stamp slots
+  const bool stamped = stamp.on;
+  const int key = B * 4 + (keep_q ? 2 : 0) + (stamped ? 1 : 0);
   auto it = decode_graphs_.find(key);
   if (it == decode_graphs_.end()) {
     if (keep_q) ensure_q_last();
@@ -1025,7 +1027,9 @@ void Model<T>::decode_step_graph(hipStream_t s, int B, bool keep_q) {
     hipGraphExec_t ge = nullptr;
     HIP_TRY(hipStreamBeginCapture(cap_stream_, hipStreamCaptureModeRelaxed));
     try {
+      if (stamped) stamp.graph_begin(key);
       llm_decode_step(cap_stream_, B, keep_q);
+      if (stamped) stamp.graph_end(cap_stream_);
     } catch (...) {
       hipStreamEndCapture(cap_stream_, &g);
       if (g) hipGraphDestroy(g);
@@ -1037,6 +1041,7 @@ void Model<T>::decode_step_graph(hipStream_t s, int B, bool keep_q) {
     it = decode_graphs_.emplace(key, ge).first;
   }
   HIP_TRY(hipGraphLaunch(it->second, s));
+  if (stamped) stamp.graph_replayed(key);
 }
 
 template <typename T>

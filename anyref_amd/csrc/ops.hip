@@ -107,6 +107,113 @@ std::vector<std::pair<std::string, ProfStat>> Profiler::stats() const {
   return v;
 }
 
+// ---- kernel-side timestamps (kernels.h: Stamper) ----------------------------------------------------
+thread_local Stamper* g_stamp = nullptr;
+namespace {
+constexpr size_t kStampEager = (size_t)4096 * 512 * 2;   // u64: 4096 eager launches of 512 workgroups
+constexpr size_t kStampStride = (size_t)256 * 512 * 2;   // u64 per replay: 256 launches of 512 workgroups
+constexpr int kStampEpochs = 48;
+__global__ void stamp_bump_kernel(int* epoch) { *epoch += 1; }
+}  // namespace
+Stamper::~Stamper() {
+  if (buf_) (void)hipFree(buf_);
+  if (ctl_) (void)hipFree(ctl_);
+}
+void Stamper::enable(bool want) {
+  if (want && !buf_) {
+    eager_cap_ = kStampEager;
+    graph_off_ = eager_cap_;
+    graph_stride_ = kStampStride;
+    max_epoch_ = kStampEpochs;
+    const size_t n = eager_cap_ + graph_stride_ * max_epoch_;
+    HIP_TRY(hipMalloc((void**)&buf_, n * 8));
+    HIP_TRY(hipMemset(buf_, 0, n * 8));
+    HIP_TRY(hipMalloc((void**)&ctl_, 2 * sizeof(int)));
+    HIP_TRY(hipMemset(ctl_, 0, 2 * sizeof(int)));
+  }
+  if (want) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemset(ctl_, 0, 2 * sizeof(int)));
+    eager_.clear();
+    epoch_keys_.clear();
+    eager_used_ = 0;
+  }
+  on = want;
+}
+StampArgs Stamper::slot(const char* tag, double bytes, int grid) {
+  StampArgs a;
+  if (!on || !buf_) return a;
+  const size_t need = (size_t)grid * 2;
+  if (capturing_ >= 0) {
+    if (cap_used_ + need > graph_stride_) return a;  // step larger than the record: this launch goes unstamped
+    graphs_[capturing_].push_back({tag, bytes, grid, cap_used_});
+    a.base = buf_ + graph_off_ + cap_used_;
+    a.epoch = ctl_;
+    a.stride = (unsigned)graph_stride_;
+    a.max_epoch = max_epoch_;
+    cap_used_ += need;
+  } else {
+    if (eager_used_ + need > eager_cap_) return a;
+    eager_.push_back({tag, bytes, grid, eager_used_});
+    a.base = buf_ + eager_used_;
+    a.epoch = ctl_ + 1;
+    a.stride = 0;
+    a.max_epoch = 1;
+    eager_used_ += need;
+  }
+  return a;
+}
+void Stamper::graph_begin(int key) {
+  capturing_ = key;
+  cap_used_ = 0;
+  graphs_[key].clear();
+}
+void Stamper::graph_end(hipStream_t cap) {
+  hipLaunchKernelGGL(stamp_bump_kernel, dim3(1), dim3(1), 0, cap, ctl_);
+  capturing_ = -1;
+}
+std::vector<StampRow> Stamper::collect() {
+  std::vector<StampRow> rows;
+  if (!buf_) return rows;
+  const int E = std::min((int)epoch_keys_.size(), max_epoch_);
+  std::vector<unsigned long long> h(graph_off_ + graph_stride_ * (size_t)E);
+  if (eager_used_) HIP_TRY(hipMemcpy(h.data(), buf_, eager_used_ * 8, hipMemcpyDeviceToHost));
+  if (E) HIP_TRY(hipMemcpy(h.data() + graph_off_, buf_ + graph_off_, graph_stride_ * (size_t)E * 8, hipMemcpyDeviceToHost));
+  struct Raw { const Rec* r; unsigned long long t0, t1; int epoch; };
+  std::vector<Raw> raw;
+  auto reduce = [&](const Rec& r, size_t base, int epoch) {
+    unsigned long long t0 = ~0ull, t1 = 0;
+    for (int g = 0; g < r.grid; ++g) {
+      const unsigned long long a = h[base + (size_t)g * 2], b = h[base + (size_t)g * 2 + 1];
+      if (a == 0 || b == 0) continue;  // a workgroup slot that was never written
+      t0 = std::min(t0, a);
+      t1 = std::max(t1, b);
+    }
+    if (t1 > 0 && t0 != ~0ull) raw.push_back({&r, t0, t1, epoch});
+  };
+  for (const Rec& r : eager_) reduce(r, r.off, -1);
+  for (int e = 0; e < E; ++e)
+    for (const Rec& r : graphs_[epoch_keys_[e]]) reduce(r, graph_off_ + graph_stride_ * (size_t)e + r.off, e);
+  std::sort(raw.begin(), raw.end(), [](const Raw& a, const Raw& b) { return a.t0 < b.t0; });
+  const unsigned long long origin = raw.empty() ? 0 : raw.front().t0;
+  for (const Raw& x : raw) {
+    StampRow row;
+    row.tag = x.r->tag;
+    row.bytes = x.r->bytes;
+    row.t0_us = (double)(x.t0 - origin) * 0.01;  // 100 MHz wall clock
+    row.t1_us = (double)(x.t1 - origin) * 0.01;
+    row.epoch = x.epoch;
+    rows.push_back(row);
+  }
+  // ready for the next pass: slots back to "never written", counters to zero
+  HIP_TRY(hipMemset(buf_, 0, (graph_off_ + graph_stride_ * (size_t)max_epoch_) * 8));
+  HIP_TRY(hipMemset(ctl_, 0, 2 * sizeof(int)));
+  eager_.clear();
+  epoch_keys_.clear();
+  eager_used_ = 0;
+  return rows;
+}
+
 // ---------------------------------------------------------------------------------------------
 // LayerNorm / RMSNorm: one wave per row, two passes over registers-cached data.
 // ---------------------------------------------------------------------------------------------

@@ -66,7 +66,8 @@ def _c_config(cfg: AnyRefConfig, mode: int, max_batch: int, max_seg: int) -> _li
 
 _NEEDS_HANDLE = frozenset({
     "generate", "model_forward_new", "forward", "__call__", "encode_images", "sam_encode", "mask_decode", "llm_forward",
-    "seg_tail", "postprocess", "audio_encode", "device_bytes", "set_overlap", "set_early_tail", "set_graphs", "profile_enable", "profile_read"})
+    "seg_tail", "postprocess", "audio_encode", "device_bytes", "set_overlap", "set_early_tail", "set_graphs", "profile_enable", "profile_read",
+    "stamps_enable", "stamps_read"})
 
 
 class AnyRefForCausalLM:
@@ -364,6 +365,26 @@ class AnyRefForCausalLM:
             out[name.value.decode()] = dict(ms=ms.value, count=cnt.value, flops=fl.value, bytes=by.value)
             i += 1
         return out
+
+    def stamps_enable(self, on: bool):
+        """Kernel-side timestamps of the decode GEMVs (include/anyref_hip.h `anyref_stamps_*`): what bench.py's in-situ
+        roofline reads -- production launch path (hipGraph replay, SAM encoder co-running), no event brackets."""
+        torch.cuda.synchronize(self.device)
+        self._check(self.lib.anyref_stamps_enable(self.h, int(on)), "stamps_enable")
+
+    def stamps_read(self):
+        """-> [dict(tag, t0_us, t1_us, bytes, epoch)] of every stamped launch since enable / the last read, by start time."""
+        torch.cuda.synchronize(self.device)
+        n = _lib._L()
+        self._check(self.lib.anyref_stamps_collect(self.h, C.byref(n)), "stamps_collect")
+        name = C.create_string_buffer(128)
+        t0, t1, by, ep = C.c_double(), C.c_double(), C.c_double(), C.c_int()
+        rows = []
+        for i in range(n.value):
+            if self.lib.anyref_stamps_read(self.h, i, name, 128, C.byref(t0), C.byref(t1), C.byref(by), C.byref(ep)) != 0:
+                break
+            rows.append(dict(tag=name.value.decode(), t0_us=t0.value, t1_us=t1.value, bytes=by.value, epoch=ep.value))
+        return rows
 
     def postprocess(self, low: torch.Tensor, resized_size, original_size) -> torch.Tensor:
         """`Sam.postprocess_masks` (sam.py:137-172) on low-res logits [n, 4g, 4g] -> [n, H, W]."""

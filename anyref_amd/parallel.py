@@ -107,7 +107,7 @@ class DataParallelAnyRef:
         total = int(nseg.sum())
         if total == 0:
             return out_ids, None, (None, None, None)
-        if m.cfg.rephrase_weight > 0 and total < n:
+        if getattr(m.cfg, "rephrase_weight", 0) > 0 and total < n:
             # anyref.py:739-744,763-765 on the GLOBAL batch (what a single process would have seen): fewer [SEG]
             # tokens than samples with rephrasing on is the reference's `no_mask` return
             z = torch.zeros((1, int(height[0]), int(width[0])), device=m.device, dtype=torch.float32)

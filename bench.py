@@ -6,14 +6,17 @@
 One "step" = one `generate()` over one batch of synthetic (image, instruction) pairs per GPU:
 CLIP ViT-L/14 -> LLaVA splice -> LLaMA-7B prefill (S=320) + greedy decode (10 new tokens, KV
 cache) -> [SEG] hand-off -> SAM-H image encoder -> mask decoder -> 1024^2 mask logits, with the
-inputs already resident in HBM.  N=1 is BASELINE.json configs[1] (batch 1).  For N>1 (launched by
-torch.distributed.run, one rank per GPU) every rank runs the same per-GPU workload on its own
-images (weak scaling) and the step ends with the RCCL all-gather of the low-res mask logits +
-token ids.
+inputs already resident in HBM.  N=1 is BASELINE.json configs[1] (C2: batch 1).  For N>1 (launched by
+torch.distributed.run, one rank per GPU) the default is configs[2] (C3: the same model, 4 images per GPU
+= global batch 4 N; 32 on 8 GPUs): every rank runs the same per-GPU workload on its own images (weak
+scaling) and the step ends with the RCCL all-gather of the low-res mask logits + token ids.
 
-Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline     : the dominant kernel of the step (by summed device time), timed live with hipEvent
-                 pairs on the launch stream over the timed region
+The timed region runs what ships: hipGraph replay of the decode step, SAM encoder on the second stream,
+no profiler.  Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline     : the dominant kernel of the step (by summed device time), measured in a separate untimed
+                 pass of the same step from KERNEL-SIDE timestamps (every workgroup stamps the 100 MHz wall
+                 clock at entry / exit; include/anyref_hip.h anyref_stamps_*): in situ (frac) and with the
+                 co-running stream off (isolated, what rocprofv3 --kernel-trace --stats can check)
   cpu_baseline : the CPU oracle (oracle/anyref_oracle.py, fp32, KV cache on) timed on this host on
                  one image of the same workload (N=1 only)
   parity       : mask-logit max-abs-err and greedy-id identity of both arithmetic modes vs that
@@ -65,13 +68,20 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="c2", choices=["c2", "c4", "c5", "tiny"],
-                    help="c2: BASELINE configs[1] (the headline); c4: c2 + audio reference (raw mel clips through the ImageBind "
-                         "trunk, configs[3]); c5: 13B LLM, fp8 weights, batch 8 (configs[4]); tiny: plumbing")
+    ap.add_argument("--config", default=None, choices=["c2", "c3", "c4", "c5", "tiny"],
+                    help="c2: BASELINE configs[1] (the headline; default at --gpus 1); c3: configs[2] = c2 at 4 images per GPU "
+                         "(default at --gpus N > 1: global batch 4 N); c4: c2 + audio reference (raw mel clips through the "
+                         "ImageBind trunk, configs[3]); c5: 13B LLM, fp8 weights, batch 8 (configs[4]); tiny: plumbing")
     ap.add_argument("--audio-trunk", default="hip", choices=["hip", "torch"],
                     help="c4: ImageBind audio trunk inside the HIP handle (f-4) or as the PyTorch-ROCm module")
     ap.add_argument("--mode", default=None, choices=["perf", "perf_fp8w"], help="default: perf (bf16); c5: perf_fp8w")
-    ap.add_argument("--batch-per-gpu", type=int, default=1)
+    ap.add_argument("--batch-per-gpu", type=int, default=None, help="default: 1 (c2 / c4), 4 (c3), 8 (c5)")
+    ap.add_argument("--roofline-steps", type=int, default=3, help="steps of the untimed kernel-timestamp passes")
+    ap.add_argument("--stamps-out", default=None,
+                    help="write the per-launch kernel-timestamp table (CSV) here; default gpurun_out/stamps_<config>.csv "
+                         "when gpurun_out/ exists")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="N = 1, c2 only: skip the short c3-shape / c4 / c5 sub-measurements appended to the line")
     ap.add_argument("--max-new-tokens", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
@@ -86,6 +96,10 @@ def main():
         log(f"note: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
     if args.same_device:
         local = 0
+    if args.config is None:
+        args.config = "c2" if world == 1 else "c3"
+    # one process per GPU under torch.distributed.run: nothing may have touched HIP before the rank picks its device
+    assert not torch.cuda.is_initialized(), "HIP was initialised before the rank selected its device"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
@@ -99,195 +113,260 @@ def main():
     from anyref_amd.model import AnyRefForCausalLM
     from anyref_amd.parallel import gather_results
 
-    B, T = args.batch_per_gpu, args.max_new_tokens
-    mode = args.mode or ("perf_fp8w" if args.config == "c5" else "perf")
-    if args.config in ("c2", "c4"):
-        cfg = config_7b()
-        cfg.llm.max_seq = 512
-        S_img = 1024
-        if args.config == "c4":
-            args.no_cpu_baseline = True      # the CPU baseline / parity legs are quoted on C2
-            if args.audio_trunk == "hip":
-                from anyref_amd.config import AudioTrunkConfig
-                cfg.audio_trunk = AudioTrunkConfig()
-    elif args.config == "c5":
-        from anyref_amd.config import config_13b
-        cfg = config_13b()
-        cfg.llm.max_seq = 512
-        S_img = 1024
-        if B == 1:
-            B = 8
-        args.no_cpu_baseline = True      # the 13B fp32 oracle needs ~55 GB and minutes per image: not timed here
-    else:
-        cfg = config_tiny()
-        S_img = cfg.sam.img_size
-    t0 = time.time()
-    sd = synth_state_dict(cfg, seed=0, device=dev, dtype=torch.bfloat16)        # identical on every rank
-    clip, sam, ids = make_inputs(cfg, B, seed=1 + rank)
-    clip, sam = clip.to(dev), sam.to(dev)                                          # resident in HBM
-    sizes, H, W = [(S_img, S_img)] * B, [S_img] * B, [S_img] * B
-    gen_kw = {}
-    if args.config == "c4":
-        # AVSBench-style prompt: 3 <audio_ref> placeholders (utils/avsbench.py:256-259), raw mel clips [1,3,1,128,204]
-        from anyref_amd.config import AUDIO_REF_INDEX
-        ids = torch.cat([ids[:, :5], torch.full((B, 3), AUDIO_REF_INDEX), ids[:, 5:-3]], 1)
-        mels = [torch.randn(1, 3, 1, 128, 204, generator=torch.Generator().manual_seed(9 + b)).to(dev) for b in range(B)]
-        gen_kw["audios"] = mels
-    model = AnyRefForCausalLM.from_state_dict(cfg, sd, mode=mode, device=local, max_batch=B, max_seg=2)
-    model.config.eos_token_id = None                                               # fixed work: T new tokens
-    if args.config == "c4" and args.audio_trunk == "torch":
-        from anyref_amd.audio import ImageBindAudio
-        torch.manual_seed(0)
-        model.audio_encoder = ImageBindAudio().eval().to(dev)
-    torch.cuda.synchronize()
-    log(f"[bench] weights + perf model ready in {time.time() - t0:.1f}s, {model.device_bytes / 2**30:.1f} GiB on device")
-
-    # name the id the random model emits at decode step 3 as [SEG]
-    out_ids, _, _ = model.generate(clip, ids, sam, sizes, H, W, max_new_tokens=T, **gen_kw)
-    seg_id = int(out_ids[0, ids.shape[1] + 2])
-    model.set_seg_token_idx(seg_id)
-
-    n_global = B * world
-    Lout = ids.shape[1] + T
-
-    def step():
-        if world == 1:
-            oids, masks, _ = model.generate(clip, ids, sam, sizes, H, W, max_new_tokens=T, **gen_kw)
-            return oids, masks
-        (oids, masks, _), ex = model.generate(clip, ids, sam, sizes, H, W, max_new_tokens=T, _return_extras="low", **gen_kw)
-        if world > 1:
-            idp = torch.zeros(B, Lout, dtype=torch.long, device=dev)
-            idp[:, : oids.shape[1]] = oids
-            gather_results(ex["low_res"], ex["nseg"].to(dev), idp, ex["out_lens"].to(dev), n_global)
-        return oids, masks
-
-    for _ in range(args.warmup):
-        step()
-    # pre-pass: which kernel dominates the step?  Tags are per kernel INSTANTIATION (what rocprofv3 lists);
-    # the dominant kernel is the kernel template whose instantiations sum to the most device time.
-    def family(tag):
-        return "_".join(tag.split("_")[:2])              # gemv_bf16_swiglu_x8 -> gemv_bf16
-
-    model.profile_enable(True)
-    step()
-    table = model.profile_read()
-    model.profile_enable(False)
-    fam_ms = {}
-    for k, v in table.items():
-        fam_ms[family(k)] = fam_ms.get(family(k), 0.0) + v["ms"]
-    dom = max(fam_ms, key=fam_ms.get) if fam_ms else None
+    T = args.max_new_tokens
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # hipEvent pairs around every 48th launch of the dominant kernel during the timed region (timing every
-    # launch of every kernel costs ~4 us of dispatch gap each: 10 ms per step at 2300 launches, 0.3 ms at every 16th GEMV, 0.1 ms at every 48th)
-    model.profile_enable(True, only_tag=dom, sample_every=48)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        oids, masks = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    timed = {k: v for k, v in model.profile_read().items() if v["count"]}
-    model.profile_enable(False)
-    # the same kernel without a co-running stream (one extra, untimed step): the timed region overlaps the
-    # SAM encoder with the decode loop, which inflates every co-running kernel's duration
-    iso = {}
-    if dom:
-        model.set_overlap(False)
+    def family(tag):
+        return "_".join(tag.split("_")[:2])              # gemv_bf16_swiglu_x8 -> gemv_bf16
+
+    def measure(config, steps, warmup, B=None, mode=None, roofline_steps=3, stamps_out=None, full=True):
+        """Build `config`, time `steps` steps of it on the production path, then (untimed) measure its dominant
+        kernel.  -> (result dict, context for the CPU / parity legs)."""
+        mode = mode or args.mode or ("perf_fp8w" if config == "c5" else "perf")
+        B = B or {"c3": 4, "c5": 8}.get(config, 1)
+        if config in ("c2", "c3", "c4"):
+            cfg = config_7b()
+            cfg.llm.max_seq = 512
+            S_img = 1024
+            if config == "c4" and args.audio_trunk == "hip":
+                from anyref_amd.config import AudioTrunkConfig
+                cfg.audio_trunk = AudioTrunkConfig()
+        elif config == "c5":
+            from anyref_amd.config import config_13b
+            cfg = config_13b()
+            cfg.llm.max_seq = 512
+            S_img = 1024
+        else:
+            cfg = config_tiny()
+            S_img = cfg.sam.img_size
+        t0 = time.time()
+        sd = synth_state_dict(cfg, seed=0, device=dev, dtype=torch.bfloat16)        # identical on every rank
+        clip, sam, ids = make_inputs(cfg, B, seed=1 + rank)
+        clip, sam = clip.to(dev), sam.to(dev)                                          # resident in HBM
+        sizes, H, W = [(S_img, S_img)] * B, [S_img] * B, [S_img] * B
+        gen_kw = {}
+        if config == "c4":
+            # AVSBench-style prompt: 3 <audio_ref> placeholders (utils/avsbench.py:256-259), raw mel clips [1,3,1,128,204]
+            from anyref_amd.config import AUDIO_REF_INDEX
+            ids = torch.cat([ids[:, :5], torch.full((B, 3), AUDIO_REF_INDEX), ids[:, 5:-3]], 1)
+            gen_kw["audios"] = [torch.randn(1, 3, 1, 128, 204, generator=torch.Generator().manual_seed(9 + b)).to(dev)
+                                for b in range(B)]
+        model = AnyRefForCausalLM.from_state_dict(cfg, sd, mode=mode, device=local, max_batch=B, max_seg=2)
+        model.config.eos_token_id = None                                               # fixed work: T new tokens
+        if config == "c4" and args.audio_trunk == "torch":
+            from anyref_amd.audio import ImageBindAudio
+            torch.manual_seed(0)
+            model.audio_encoder = ImageBindAudio().eval().to(dev)
+        torch.cuda.synchronize()
+        log(f"[bench:{config}] weights + {mode} model ready in {time.time() - t0:.1f}s, {model.device_bytes / 2**30:.1f} GiB on device")
+
+        # SURVEY.md §8c-3: name the id the random model emits at decode step 3 as [SEG]
+        out_ids, _, _ = model.generate(clip, ids, sam, sizes, H, W, max_new_tokens=T, **gen_kw)
+        seg_id = int(out_ids[0, ids.shape[1] + 2])
+        model.set_seg_token_idx(seg_id)
+        n_global = B * world
+        Lout = ids.shape[1] + T
+
+        def step():
+            if world == 1:
+                oids, masks, _ = model.generate(clip, ids, sam, sizes, H, W, max_new_tokens=T, **gen_kw)
+                return oids, masks
+            (oids, masks, _), ex = model.generate(clip, ids, sam, sizes, H, W, max_new_tokens=T, _return_extras="low", **gen_kw)
+            idp = torch.zeros(B, Lout, dtype=torch.long, device=dev)
+            idp[:, : oids.shape[1]] = oids
+            gather_results(ex["low_res"], ex["nseg"].to(dev), idp, ex["out_lens"].to(dev), n_global)
+            return oids, masks
+
+        for _ in range(warmup):
+            step()
+        # ---- the timed region: what ships (hipGraph decode step, two streams, no profiler, no stamps) ----
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        barrier()
+        dt = time.perf_counter() - t0
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
+        if world > 1:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        ips = n_global * steps / dt
+
+        # ---- untimed: per-kernel table of one step (hipEvent brackets, eager launches) -> the dominant kernel.
+        # Tags are per kernel INSTANTIATION (what rocprofv3 lists); the dominant kernel is the kernel template whose
+        # instantiations sum to the most device time.
+        model.profile_enable(True)
         step()
-        model.profile_enable(True, only_tag=dom, sample_every=1)
-        step()
-        iso = {k: v for k, v in model.profile_read().items() if v["count"]}
+        table = model.profile_read()
         model.profile_enable(False)
-        model.set_overlap(True)
-    tt = torch.tensor([dt], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
-    if world > 1:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    dt = float(tt.item())
-    ips = n_global * args.steps / dt
+        fam_ms = {}
+        for k, v in table.items():
+            fam_ms[family(k)] = fam_ms.get(family(k), 0.0) + v["ms"]
+        dom = max(fam_ms, key=fam_ms.get) if fam_ms else None
 
-    roofline = None
-    if dom and timed:
-        compute = dom.startswith(("gemm", "attn"))
-        peak = (PEAK_BF16_TFLOPS if "bf16" in dom else PEAK_F32_TFLOPS) if compute else PEAK_HBM_GBS
-        unit = "TFLOP/s" if compute else "GB/s"
+        # ---- untimed: the dominant kernel's duration from KERNEL-SIDE timestamps on the production launch path
+        # (graph replay, encoder co-running): frac; then the same with the co-running stream off: isolated
+        def stamp_pass(n):
+            model.stamps_enable(True)
+            step()                                   # first stamped step captures the stamped graph: not recorded
+            model.stamps_read()
+            for _ in range(n):
+                step()
+            rows = model.stamps_read()
+            model.stamps_enable(False)
+            return rows
 
-        def rate(v):  # algorithmic FLOPs (or bytes) of the timed launches / their summed duration
-            return (v["flops"] / 1e12 if compute else v["bytes"] / 1e9) / (v["ms"] / 1e3)
+        def by_tag(rows):
+            out = {}
+            for r in rows:
+                d = out.setdefault(r["tag"], dict(us=0.0, count=0, bytes=0.0))
+                d["us"] += r["t1_us"] - r["t0_us"]
+                d["count"] += 1
+                d["bytes"] += r["bytes"]
+            return out
 
-        def total(d):
-            return {f: sum(v[f] for v in d.values()) for f in ("ms", "count", "flops", "bytes")}
+        roofline = None
+        rows = stamp_pass(roofline_steps) if dom and dom.startswith("gemv") and roofline_steps > 0 else []
+        if rows:
+            situ = by_tag(rows)
+            tot_us, tot_n, tot_b = (sum(v[f] for v in situ.values()) for f in ("us", "count", "bytes"))
+            ach = tot_b / 1e9 / (tot_us / 1e6)
+            per_step = sum(v["count"] for k, v in table.items() if family(k) == dom)
+            roofline = dict(kernel=dom, bound="hbm", achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit="GB/s",
+                            frac=round(ach / PEAK_HBM_GBS, 4), traffic=None, traffic_source=None,
+                            source="kernel-side timestamps (100 MHz wall clock stamped by every workgroup; launch = "
+                                   "max(end) - min(start)) over an untimed pass of the production path: hipGraph replay, "
+                                   "SAM encoder co-running on the second stream",
+                            launches_per_step=per_step, timed_launches=tot_n, avg_launch_us=round(tot_us / tot_n, 2),
+                            algorithmic_bytes_per_launch=round(tot_b / tot_n),
+                            share_of_step=round(tot_us / roofline_steps / 1e3 / (dt / steps * 1e3), 3))
+            roofline["instantiations"] = {
+                k: dict(launches_per_step=round(v["count"] / roofline_steps), avg_launch_us=round(v["us"] / v["count"], 2),
+                        achieved=round(v["bytes"] / 1e9 / (v["us"] / 1e6), 1),
+                        algorithmic_bytes_per_launch=round(v["bytes"] / v["count"])) for k, v in sorted(situ.items())}
+            # gaps between consecutive stamped launches of one captured step (what a kernel boundary + the attention
+            # launch between two GEMVs cost): reported, not part of `achieved`
+            gaps = sorted(b["t0_us"] - a["t1_us"] for a, b in zip(rows, rows[1:]) if a["epoch"] == b["epoch"] and a["epoch"] >= 0)
+            if gaps:
+                roofline["gap_between_launches_us"] = dict(median=round(gaps[len(gaps) // 2], 2),
+                                                           p10=round(gaps[len(gaps) // 10], 2),
+                                                           p90=round(gaps[len(gaps) * 9 // 10], 2))
+            model.set_overlap(False)
+            iso_rows = stamp_pass(1)
+            model.set_overlap(True)
+            iso = by_tag(iso_rows)
+            iu, inn, ib = (sum(v[f] for v in iso.values()) for f in ("us", "count", "bytes"))
+            roofline["isolated"] = {
+                "achieved": round(ib / 1e9 / (iu / 1e6), 1), "frac": round(ib / 1e9 / (iu / 1e6) / PEAK_HBM_GBS, 4),
+                "avg_launch_us": round(iu / inn, 2),
+                "instantiations": {k: dict(avg_launch_us=round(v["us"] / v["count"], 2),
+                                           achieved=round(v["bytes"] / 1e9 / (v["us"] / 1e6), 1)) for k, v in sorted(iso.items())},
+                "note": "same kernels, same launch path, SAM-encoder overlap off (no co-running stream): the figure "
+                        "rocprofv3 --kernel-trace --stats can check (profiles/r03_*kernel_stats.csv); rocprofv3's duration "
+                        "includes the dispatch ramp in front of the first wave, the stamps do not"}
+            # HBM traffic from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command
+            # (tools/pmc_summary.py -> profiles/pmc_traffic.json; counters cannot be read inside a timed run),
+            # averaged over the kernel's launches of one step
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+                if config == "c2" and B == 1 and mode == "perf" and all(k in pmc for k in situ):
+                    n = sum(table[k]["count"] for k in situ if k in table)
+                    roofline["traffic"] = round(sum(pmc[k]["hbm_bytes_per_launch"] * table[k]["count"] for k in situ if k in table) / n)
+                    roofline["traffic_source"] = ("committed file profiles/pmc_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / "
+                                                  "WRITE_SIZE passes of this command, FETCH_SIZE doubled per the guide's gfx950 "
+                                                  "correction); not collected by this run")
+            except (OSError, ValueError, KeyError):
+                pass
+            out_path = stamps_out
+            if out_path is None and os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+                out_path = os.path.join(ROOT, "gpurun_out", f"stamps_{config}.csv")
+            if out_path and rank == 0:
+                with open(out_path, "w") as f:
+                    f.write("pass,step_replay,tag,start_us,end_us,duration_us,algorithmic_bytes,GBps\n")
+                    for name, rr in (("in_situ", rows), ("isolated", iso_rows)):
+                        for r in rr:
+                            d = r["t1_us"] - r["t0_us"]
+                            f.write(f"{name},{r['epoch']},{r['tag']},{r['t0_us']:.2f},{r['t1_us']:.2f},{d:.2f},{r['bytes']:.0f},"
+                                    f"{r['bytes'] / 1e3 / max(d, 1e-9):.1f}\n")
+                roofline["per_launch_table"] = os.path.relpath(out_path, ROOT)
+        elif dom:
+            # a compute-bound dominant kernel (large batches): hipEvent brackets of an eager pass, overlap off
+            compute = dom.startswith(("gemm", "attn"))
+            peak = (PEAK_BF16_TFLOPS if "bf16" in dom else PEAK_F32_TFLOPS) if compute else PEAK_HBM_GBS
+            sel = {k: v for k, v in table.items() if family(k) == dom and v["count"]}
+            ms = sum(v["ms"] for v in sel.values())
+            work = sum(v["flops"] / 1e12 if compute else v["bytes"] / 1e9 for v in sel.values())
+            ach = work / (ms / 1e3)
+            roofline = dict(kernel=dom, bound="mfma" if compute else "hbm", achieved=round(ach, 1), peak=peak,
+                            unit="TFLOP/s" if compute else "GB/s", frac=round(ach / peak, 4), traffic=None, traffic_source=None,
+                            source="hipEvent brackets over one eager, untimed step",
+                            launches_per_step=sum(v["count"] for v in sel.values()))
+        breakdown = {k: dict(ms_per_step=round(v["ms"], 3), launches=v["count"],
+                             tflops=round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 1),
+                             gbs=round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1)) for k, v in sorted(
+            table.items(), key=lambda kv: -kv[1]["ms"])}
+        workload = {"c2": "C2: LLaVA-7B + CLIP ViT-L/14 + SAM-H refer-seg forward, 1024x1024, S=320 prompt, "
+                          f"{T} new tokens, KV cache",
+                    "c3": f"C3: C2 at {B} images per GPU, batch-sharded data parallel: global batch {B}*N = {n_global} "
+                          f"({B * 8} on 8 GPUs), all-gather of mask logits + ids per step; S=320 prompts, {T} new tokens, KV cache",
+                    "c4": "C4: C2 + audio reference: 3 raw mel clips [1,3,1,128,204] -> ImageBind audio trunk "
+                          f"({'HIP, inside the handle' if args.audio_trunk == 'hip' else 'PyTorch-ROCm module'}) -> "
+                          f"audio_projector -> 3 <audio_ref> slots; S=320 prompt, {T} new tokens, KV cache",
+                    "c5": "C5: 13B LLM + CLIP ViT-L/14 + SAM-H refer-seg forward, fp8-weight LLM, 1024x1024, S=320 "
+                          f"prompt, {T} new tokens, KV cache",
+                    "tiny": "C1 tiny plumbing config"}[config]
+        res = {
+            "metric": {"c2": "images/sec (1024^2, 7B LLM+ViT-L+SAM-H)", "c3": "images/sec (1024^2, 7B LLM+ViT-L+SAM-H)",
+                       "c4": "images/sec (1024^2, 7B LLM+ViT-L+SAM-H, audio-referred: ImageBind audio trunk + 3 audio tokens)",
+                       "c5": "images/sec (1024^2, 13B LLM+ViT-L+SAM-H, fp8 weights)",
+                       "tiny": "images/sec (tiny plumbing config)"}[config],
+            "value": round(ips, 3), "unit": "images/sec", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16" if mode == "perf" else "bf16 (LLM linear weights fp8 e4m3, weight-only)",
+            "data": "synthetic",
+            "config": {"workload": workload, "batch_per_gpu": B, "global_batch": n_global, "parallelism": f"dp{world}",
+                       "max_new_tokens": T, "weights": "random-init N(0,0.02^2) rounded to bf16",
+                       "launch_path": "hipGraph decode step, SAM encoder on a second stream, profiler off"},
+            "roofline": roofline,
+        }
+        if full:
+            res["kernel_breakdown"] = breakdown
+        if config == "c2" and T == 10 and mode == "perf" and ids.shape[1] == 65:
+            # SURVEY.md §8d: algorithmic FLOPs of one image (S = 320, T = 10, bf16) x images/s over the dense bf16 MFMA peak
+            res["mfma_frac_e2e"] = round(FLOP_PER_IMAGE_C2 * ips / world / (PEAK_BF16_TFLOPS * 1e12), 4)
+            res["flop_per_image"] = FLOP_PER_IMAGE_C2
+        ctx = dict(cfg=cfg, sd=sd, model=model, clip=clip, sam=sam, ids=ids, sizes=sizes, H=H, W=W, B=B, mode=mode)
+        return res, ctx
 
-        tot = total(timed)
-        ach = rate(tot)
-        roofline = dict(kernel=dom, bound="mfma" if compute else "hbm", achieved=round(ach, 2 if compute else 1), peak=peak,
-                        unit=unit, frac=round(ach / peak, 4), traffic=None)
-        per_step = sum(v["count"] for k, v in table.items() if family(k) == dom)
-        roofline.update(event_pair_overhead_us=round(getattr(model, "profile_overhead_us", 0.0), 2),
-                        launches_per_step=per_step, timed_launches=tot["count"],
-                        avg_launch_us=round(tot["ms"] * 1e3 / tot["count"], 2),
-                        algorithmic_bytes_per_launch=round(tot["bytes"] / tot["count"]),
-                        share_of_step=round(tot["ms"] / tot["count"] * per_step * args.steps / 1e3 / dt, 3))
-        # per instantiation: what to hold against rocprofv3 --kernel-trace --stats (profiles/)
-        roofline["instantiations"] = {
-            k: dict(launches_per_step=table[k]["count"], avg_launch_us=round(v["ms"] * 1e3 / v["count"], 2),
-                    achieved=round(rate(v), 1), algorithmic_bytes_per_launch=round(v["bytes"] / v["count"]))
-            for k, v in sorted(timed.items())}
-        roofline["note"] = ("frac = live hipEvent brackets in the timed region, where the SAM encoder co-runs on the second stream "
-                            "and inflates the GEMVs; rocprofv3 serialises the two streams (profiles/r02_overlap_under_rocprof.txt: "
-                            "<1 % of GEMV launches overlap another queue's kernel), so its per-kernel averages "
-                            "(profiles/r02_*kernel_stats.csv) check `isolated`, not the in-situ figure")
-        if iso:
-            ti = total(iso)
-            roofline["isolated"] = {"achieved": round(rate(ti), 1), "frac": round(rate(ti) / peak, 4),
-                                    "avg_launch_us": round(ti["ms"] * 1e3 / ti["count"], 2),
-                                    "instantiations": {k: dict(avg_launch_us=round(v["ms"] * 1e3 / v["count"], 2),
-                                                               achieved=round(rate(v), 1)) for k, v in sorted(iso.items())},
-                                    "note": "same kernels, SAM-encoder overlap off (no co-running stream)"}
-        # HBM traffic from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command
-        # (tools/pmc_summary.py -> profiles/pmc_traffic.json; counters cannot be read inside a timed run),
-        # averaged over the kernel's launches of one step
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            if args.config == "c2" and all(k in pmc for k in timed):
-                n = sum(table[k]["count"] for k in timed)
-                roofline["traffic"] = round(sum(pmc[k]["hbm_bytes_per_launch"] * table[k]["count"] for k in timed) / n)
-        except (OSError, ValueError, KeyError):
-            pass
-    breakdown = {k: dict(ms_per_step=round(v["ms"], 3), launches=v["count"],
-                         tflops=round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 1),
-                         gbs=round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1)) for k, v in sorted(
-        table.items(), key=lambda kv: -kv[1]["ms"])}
+    res, ctx = measure(args.config, args.steps, args.warmup, B=args.batch_per_gpu, roofline_steps=args.roofline_steps,
+                       stamps_out=args.stamps_out)
+    if args.config in ("c4", "c5", "c3"):
+        args.no_cpu_baseline = True      # the CPU baseline / parity legs are quoted on C2 (13B fp32 needs ~55 GB of host memory)
+    cfg, sd, model, clip, sam, ids, sizes, H, W = (ctx[k] for k in ("cfg", "sd", "model", "clip", "sam", "ids", "sizes", "H", "W"))
+    mode = ctx["mode"]
 
-    res = {
-        "metric": {"c2": "images/sec (1024^2, 7B LLM+ViT-L+SAM-H)",
-                   "c4": "images/sec (1024^2, 7B LLM+ViT-L+SAM-H, audio-referred: ImageBind audio trunk + 3 audio tokens)", "c5": "images/sec (1024^2, 13B LLM+ViT-L+SAM-H, fp8 weights)",
-                   "tiny": "images/sec (tiny plumbing config)"}[args.config],
-        "value": round(ips, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "bf16" if mode == "perf" else "bf16 (LLM linear weights fp8 e4m3, weight-only)",
-        "data": "synthetic",
-        "config": {"workload": {"c2": "C2: LLaVA-7B + CLIP ViT-L/14 + SAM-H refer-seg forward, 1024x1024, S=320 prompt, "
-                                      f"{T} new tokens, KV cache",
-                                "c4": "C4: C2 + audio reference: 3 raw mel clips [1,3,1,128,204] -> ImageBind audio trunk "
-                                      f"({'HIP, inside the handle' if args.audio_trunk == 'hip' else 'PyTorch-ROCm module'}) -> "
-                                      f"audio_projector -> 3 <audio_ref> slots; S=320 prompt, {T} new tokens, KV cache",
-                                "c5": "C5: 13B LLM + CLIP ViT-L/14 + SAM-H refer-seg forward, fp8-weight LLM, 1024x1024, S=320 "
-                                      f"prompt, {T} new tokens, KV cache",
-                                "tiny": "C1 tiny plumbing config"}[args.config],
-                   "batch_per_gpu": B, "global_batch": n_global, "parallelism": f"dp{world}",
-                   "max_new_tokens": T, "weights": "random-init N(0,0.02^2) rounded to bf16"},
-        "roofline": roofline,
-        "kernel_breakdown": breakdown,
-    }
-    if args.config == "c2":
-        # algorithmic FLOPs of one image (S = 320, T = 10) x images/s over the dense bf16 MFMA peak
-        res["mfma_frac_e2e"] = round(FLOP_PER_IMAGE_C2 * ips / world / (PEAK_BF16_TFLOPS * 1e12), 4)
-        res["flop_per_image"] = FLOP_PER_IMAGE_C2
+    # ---- driver-visible secondary lines (N = 1, headline config only): the other single-GPU configurations, short ----
+    if world == 1 and args.config == "c2" and not args.no_secondary and os.environ.get("ANYREF_BENCH_SECONDARY", "1") != "0":
+        log("[bench] GPU leg: " + json.dumps({k: res[k] for k in ("value", "ms_per_step", "roofline")}))
+        secondary = {}
+        import gc
+        for name, conf in (("c3_shape", "c3"), ("c4", "c4"), ("c5", "c5")):
+            try:
+                r2, c2 = measure(conf, 5, 2, roofline_steps=1, stamps_out="", full=False)
+                del c2
+                secondary[name] = {k: r2[k] for k in ("metric", "value", "ms_per_step", "dtype", "config", "roofline")}
+            except Exception as e:          # a secondary line must never cost the headline
+                secondary[name] = {"error": repr(e)}
+            gc.collect()
+            torch.cuda.empty_cache()
+        secondary["note"] = ("5 timed steps each on this GPU, same production launch path; c3_shape = configs[2]'s per-GPU shape "
+                             "(4 images per call) on one GPU; parity of these shapes: tests/test_gpu_e2e.py, test_gpu_audio.py, "
+                             "test_gpu_fp8w.py")
+        res["secondary"] = secondary
 
     # ---------------- CPU baseline + parity against it (rank 0, N=1 only) ----------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -297,7 +376,6 @@ def main():
         # makes the fp32 oracle many times slower
         cores = int(os.environ.get("ANYREF_CPU_THREADS", min(16, os.cpu_count() or 1)))
         torch.set_num_threads(cores)
-        log("[bench] GPU leg: " + json.dumps({k: res[k] for k in ("value", "ms_per_step", "roofline")}))
         one = (clip[:1], ids[0], sam[:1], sizes[:1], H[:1], W[:1])
 
         def mode_model(sd_, cfg_, mode_):

@@ -224,6 +224,23 @@ int anyref_profile_calibrate(anyref_handle* h, void* stream, double* overhead_us
 int anyref_profile_read(anyref_handle* h, int idx, char* name, int cap, double* ms, int64_t* count,
                         double* flops, double* bytes);
 
+/*
+ * Kernel-side timestamps for the measurement harness (bench.py "roofline", in situ): hipEvent brackets cannot be
+ * placed inside a replayed hipGraph and rocprofv3 serialises the call's two streams, so neither sees a decode GEMV
+ * as it runs in production.  With stamps enabled every decode-GEMV workgroup writes {earliest wave start, latest
+ * wave end} of the 100 MHz wall clock into its own slot (plain stores); a launch's duration is max(end) - min(start)
+ * over its workgroups.  Works inside graph replay (the captured step is re-captured with stamp slots addressed by a
+ * device-side replay counter) and beside the second stream.  Costs one uniform branch when off.
+ * anyref_stamps_collect() (after the caller has synchronised the device) reduces the slots and returns the number of
+ * launches recorded since enable / the last collect, in start-time order; anyref_stamps_read(idx) returns one launch:
+ * tag (the rocprofv3-visible instantiation, as in anyref_profile_read), start / end in microseconds relative to the
+ * first launch, algorithmic bytes, and the replay index of its captured step (-1: eager launch).
+ */
+int anyref_stamps_enable(anyref_handle* h, int on);
+int anyref_stamps_collect(anyref_handle* h, int64_t* count);
+int anyref_stamps_read(anyref_handle* h, int64_t idx, char* name, int cap, double* t0_us, double* t1_us,
+                       double* bytes, int* epoch);
+
 /* Bytes of HBM the handle holds (weights + workspaces), for sizing reports. */
 int64_t anyref_device_bytes(anyref_handle* h);
 /* Name of the compute mode's arithmetic ("f32" / "bf16"). */

@@ -240,3 +240,26 @@ def test_avs_cut_logits_are_exact_crossovers():
     assert bool((sig(cuts[1:]) >= th[1:]).all()) and not bool((sig(below) >= th[1:]).any())
     c = torch.tensor([cut_pred])
     assert bool(sig(c) > 0.5) and not bool(sig(torch.nextafter(c, torch.tensor([-1.0]))) > 0.5)
+
+
+def test_label_rows_are_cut_where_their_id_rows_were():
+    """Batched callers pass left-padded ids and no mask (eval_referseg.py:124-137): the pad rule `ids != pad` picks the
+    kept positions, and `labels` (-100 / ids, never equal to pad) must be cut at the SAME positions, or the LM loss and
+    `where(labels > 0)[0][0]` (anyref.py:378) shift against the ids."""
+    import torch
+    from anyref_amd.config import config_tiny
+    from anyref_amd.model import AnyRefForCausalLM
+    m = AnyRefForCausalLM(config_tiny(), defer=True)
+    pad = m.config.pad_token_id
+    ids = torch.tensor([[pad, pad, pad, 1, 5, 6, 7], [1, 9, 8, 7, 6, 5, 4]])
+    labels = torch.tensor([[-100, -100, -100, -100, -100, 6, 7], [-100, -100, -100, 7, 6, 5, 4]])
+    keeps = []
+    rows, lens = m._rows(ids, None, keep_out=keeps)
+    lab, lab_lens = m._rows(labels, None, keep_in=keeps)
+    assert lens.tolist() == lab_lens.tolist() == [4, 7]
+    assert rows[0, :4].tolist() == [1, 5, 6, 7] and lab[0, :4].tolist() == [-100, -100, 6, 7]
+    assert int((lab[0, :4] > 0).nonzero()[0]) == 2          # first supervised position, in the un-padded frame
+    mask = torch.tensor([[0, 0, 0, 1, 1, 1, 1], [1, 1, 1, 1, 1, 1, 1]]).bool()
+    keeps2 = []
+    rows2, _ = m._rows(ids, mask, keep_out=keeps2)
+    assert torch.equal(rows2, rows) and [k.tolist() for k in keeps2] == [k.tolist() for k in keeps]

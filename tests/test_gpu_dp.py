@@ -101,3 +101,60 @@ def test_bench_two_ranks_same_device_smoke():
     res = json.loads(line)
     assert res["n_gpus"] == 2 and res["steps"] == 2 and res["scaling"] == "weak" and res["value"] > 0
     assert res["config"]["global_batch"] == 2 * res["config"]["batch_per_gpu"]
+
+
+_RCCL_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+sys.path.insert(0, sys.argv[1])
+from anyref_amd.config import config_tiny, IMAGE_TOKEN_INDEX
+from anyref_amd.model import AnyRefForCausalLM
+from anyref_amd.parallel import gather_results
+from anyref_amd.synth import synth_state_dict
+assert not torch.cuda.is_initialized()                     # the rank picks its device before anything touches HIP
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:" + sys.argv[2], rank=0, world_size=1, device_id=dev)
+cfg = config_tiny()
+sd = synth_state_dict(cfg, seed=5, scale=0.05)
+g = torch.Generator().manual_seed(6)
+n = 3
+clip = torch.randn(n, 3, 224, 224, generator=g)
+sam = torch.randn(n, 3, 224, 224, generator=g)
+ids = torch.stack([torch.cat([torch.tensor([1, IMAGE_TOKEN_INDEX]), torch.randint(3, 990, (10,), generator=g)]) for _ in range(n)])
+sizes, H, W = [(224, 224 - 8 * b) for b in range(n)], [200 + 7 * b for b in range(n)], [180 + 11 * b for b in range(n)]
+m = AnyRefForCausalLM.from_state_dict(cfg, {k: v.cuda() for k, v in sd.items()}, mode="parity", max_batch=n, max_seg=4)
+m.config.eos_token_id = None
+o0, _, _ = m.generate(clip, ids, sam, sizes, H, W, max_new_tokens=5)
+m.set_seg_token_idx(int(o0[0, ids.shape[1] + 2]))
+(oids, masks, _), ex = m.generate(clip, ids, sam, sizes, H, W, max_new_tokens=5, _return_extras="low")
+assert masks is not None
+Lout = ids.shape[1] + 5
+idp = torch.zeros(n, Lout, dtype=torch.long, device=dev)
+idp[:, : oids.shape[1]] = oids
+low, nseg, gids, glen = gather_results(ex["low_res"], ex["nseg"].to(dev), idp, ex["out_lens"].to(dev), n)   # RCCL, device tensors
+torch.cuda.synchronize()
+assert low.is_cuda and torch.equal(low, ex["low_res"]) and torch.equal(gids, idp)
+assert torch.equal(nseg.cpu(), ex["nseg"]) and torch.equal(glen.cpu(), ex["out_lens"])
+for b in range(n):                                           # full-resolution masks re-created from the gathered logits
+    k = int(nseg[b])
+    assert torch.equal(m.postprocess(low[b, :k], sizes[b], (H[b], W[b])), masks[b]), b
+t = torch.ones(4, device=dev)
+dist.all_reduce(t)                                           # bench.py's max-over-ranks reduction path
+dist.barrier()
+dist.destroy_process_group()
+print("OK rccl", dist.is_nccl_available())
+'''
+
+
+@pytest.mark.skipif(os.environ.get("ANYREF_SKIP_RCCL_TEST") == "1", reason="ANYREF_SKIP_RCCL_TEST=1")
+def test_gather_results_over_rccl_world_size_1(tmp_path):
+    """`gather_results` over backend="nccl" (= RCCL) with a world of one on the test box's GPU: RCCL initialisation with
+    `device_id`, the in-place `all_gather_into_tensor` on DEVICE tensors (the path gloo never takes: it stages through
+    the host) and the all-reduce / barrier `bench.py --gpus N` ends with.  No scaling is measured here."""
+    script = tmp_path / "w.py"
+    script.write_text(_RCCL_WORKER)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, str(script), ROOT, str(35500 + os.getpid() % 2000)], env=env, capture_output=True,
+                         text=True, timeout=900)
+    assert out.returncode == 0 and "OK rccl" in out.stdout, (out.stdout[-2000:], out.stderr[-3000:])

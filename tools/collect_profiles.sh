@@ -10,18 +10,18 @@ R=$(pwd)
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 W=/tmp/anyref_prof; rm -rf $W; mkdir -p $W
-python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.err" || exit 1
-rocprofv3 --kernel-trace --stats --output-format csv -d $W/kt -o kt -- python3 bench.py --no-cpu-baseline --no-parity > $W/kt.json 2> $W/kt.err || exit 2
+python3 bench.py --stamps-out "$OUT/gemv_stamps_c2.csv" > "$OUT/bench.json" 2> "$OUT/bench.err" || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $W/kt -o kt -- python3 bench.py --no-cpu-baseline --no-parity --no-secondary > $W/kt.json 2> $W/kt.err || exit 2
 cp $W/kt/kt_kernel_stats.csv "$OUT/kt_kernel_stats.csv" 2>/dev/null || cp $(ls $W/kt/*kernel_stats.csv $W/kt/*/*kernel_stats.csv 2>/dev/null | head -1) "$OUT/kt_kernel_stats.csv"
-rocprofv3 --kernel-trace --stats --output-format csv -d $W/pd -o pd -- python3 scratch/prof_decode.py > /dev/null 2>&1 || exit 3
+rocprofv3 --kernel-trace --stats --output-format csv -d $W/pd -o pd -- python3 tools/prof_decode.py > /dev/null 2>&1 || exit 3
 cp $W/pd/pd_kernel_stats.csv "$OUT/pd_kernel_stats.csv" 2>/dev/null || cp $(ls $W/pd/*kernel_stats.csv $W/pd/*/*kernel_stats.csv 2>/dev/null | head -1) "$OUT/pd_kernel_stats.csv"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $W/pmc_fetch -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-parity > $W/pf.json 2> $W/pf.err || exit 4
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $W/pmc_write -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-parity > $W/pw.json 2> $W/pw.err || exit 5
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $W/pmc_fetch -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-parity --no-secondary --roofline-steps 0 > $W/pf.json 2> $W/pf.err || exit 4
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $W/pmc_write -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-parity --no-secondary --roofline-steps 0 > $W/pw.json 2> $W/pw.err || exit 5
 python3 tools/pmc_summary.py $W/pmc_fetch $W/pmc_write "$OUT/pmc_traffic.json" > /dev/null || exit 6
 # per-(kernel, grid) table with the overlap off, and what the profiler sees of the two-stream overlap
-rocprofv3 --kernel-trace --output-format csv -d $W/kt0 -o kt0 -- python3 scratch/prof_c2.py --iters 3 > /dev/null 2>&1 || exit 7
+rocprofv3 --kernel-trace --output-format csv -d $W/kt0 -o kt0 -- python3 tools/prof_c2.py --iters 3 > /dev/null 2>&1 || exit 7
 python3 tools/trace_summary.py $W/kt0 5 45 > "$OUT/kernels_by_grid_overlap_off.txt" || exit 8
-rocprofv3 --kernel-trace --output-format csv -d $W/kt1 -o kt1 -- python3 scratch/prof_c2.py --iters 3 --overlap > /dev/null 2>&1 || exit 9
+rocprofv3 --kernel-trace --output-format csv -d $W/kt1 -o kt1 -- python3 tools/prof_c2.py --iters 3 --overlap > /dev/null 2>&1 || exit 9
 python3 tools/trace_summary.py $W/kt1 5 --overlap gemv_kernel > "$OUT/overlap_under_rocprof.txt" || exit 10
 python3 - "$W" "$OUT" <<'PY'
 import collections, csv, glob, sys

@@ -1,5 +1,5 @@
 """One C2 generate per iteration for rocprofv3 --kernel-trace: overlap off by default (clean per-kernel durations),
-`--overlap` to see what co-running does.  python scratch/prof_c2.py [--overlap] [--iters N]"""
+`--overlap` to see what co-running does.  python tools/prof_c2.py [--overlap] [--iters N]"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from anyref_amd.config import config_7b

@@ -1,3 +1,5 @@
+"""41-token C2 generate, overlap and graphs off, for rocprofv3 --kernel-trace --stats: the decode GEMVs alone on the chip
+(the `isolated` figure of bench.py's roofline; tools/collect_profiles.sh -> profiles/r0N_decode_isolated_kernel_stats.csv)."""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from anyref_amd.config import config_7b
