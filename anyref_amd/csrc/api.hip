@@ -133,6 +133,7 @@ int anyref_set_overlap(anyref_handle* h, int on) { GUARD(h, h->m->set_overlap(on
 int anyref_set_early_tail(anyref_handle* h, int on) { GUARD(h, h->m->set_early_tail(on != 0)); }
 
 int anyref_set_graphs(anyref_handle* h, int on) { GUARD(h, h->m->set_graphs(on != 0)); }
+int anyref_set_side_share(anyref_handle* h, int wgs, int steps) { GUARD(h, h->m->set_side_share(wgs, steps)); }
 
 int anyref_profile_enable(anyref_handle* h, int on) {
   GUARD(h, {

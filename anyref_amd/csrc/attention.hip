@@ -125,8 +125,8 @@ __device__ inline uint32_t pack_bf16x2(float lo, float hi) { return (uint32_t)f2
 // SAM windows again -- one workgroup per (window, head) loads K and V exactly once, a single barrier, then every
 // wave walks the resident tiles on its own (the streaming form ran two query blocks per window-head, each
 // re-loading K/V through three barrier-separated tiles at one workgroup per CU: 73 us per window layer).
-template <typename T, int HD, int NWV = 4, int BKV_ = 0, int NRES = 0>
-__global__ __launch_bounds__(NWV * 64) void attn_kernel(AttnArgs a) {
+template <typename T, int HD, int NWV, int BKV_, int NRES>
+__device__ __forceinline__ void attn_body(const AttnArgs& a, const int bx, const int by, const int bz, char* smem) {
   constexpr int NT = NWV * 64;
   using M_ = AMma<T>;
   constexpr int KS = M_::KS, VEC = M_::VEC;
@@ -143,7 +143,6 @@ __global__ __launch_bounds__(NWV * 64) void attn_kernel(AttnArgs a) {
   constexpr int DB = HD / 16;                   // output d blocks
   static_assert(HD % 16 == 0, "head dim must be a multiple of 16");
 
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NTILE = NRES > 0 ? NRES : 1;  // tiles held in LDS
   T* Ks = reinterpret_cast<T*>(smem);
   T* Vs = Ks + NTILE * BKV * LDK;
@@ -155,8 +154,8 @@ __global__ __launch_bounds__(NWV * 64) void attn_kernel(AttnArgs a) {
   // kv_splits > 1 (few queries, many keys: the mask decoder's token -> image attention is 7 x 4096 on 8 heads =
   // 8 workgroups walking 128 tiles each): blockIdx.x = q-block * splits + split, every split writes an
   // un-normalised partial (O, m, l) and attn_combine_kernel merges them
-  const int split = (int)blockIdx.x % a.kv_splits;
-  const int b = blockIdx.z, h = blockIdx.y, q0 = ((int)blockIdx.x / a.kv_splits) * BQ;
+  const int split = bx % a.kv_splits;
+  const int b = bz, h = by, q0 = (bx / a.kv_splits) * BQ;
   const int kv_len = a.kv_len ? a.kv_len[b] : a.Sk;
   const int q_len = a.q_len ? a.q_len[b] : a.Sq;
   if (q0 >= q_len) return;  // uniform per workgroup
@@ -533,6 +532,23 @@ __global__ __launch_bounds__(NWV * 64) void attn_kernel(AttnArgs a) {
   }
 }
 
+template <typename T, int HD, int NWV = 4, int BKV_ = 0, int NRES = 0>
+__global__ __launch_bounds__(NWV * 64) void attn_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  attn_body<T, HD, NWV, BKV_, NRES>(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, smem);
+}
+// Capped grid (AttnArgs::max_wg workgroups): every workgroup walks the (query block, head, batch) triples
+// v, v + gridDim.x, ... -- the SAM encoder's attention on the side stream, which must leave CUs to the decode GEMVs
+// of the main stream (as gemm_glds_kernel<.., PERSIST>).  No key splits in this form.
+template <typename T, int HD, int NWV, int BKV_, int NRES>
+__global__ __launch_bounds__(NWV * 64) void attn_walk_kernel(AttnArgs a, int gx, int gy, int total) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  for (int v = blockIdx.x; v < total; v += gridDim.x) {
+    attn_body<T, HD, NWV, BKV_, NRES>(a, v % gx, (v / gx) % gy, v / (gx * gy), smem);
+    __syncthreads();  // the next triple's LDS tiles are not written before every wave has left this one
+  }
+}
+
 // merge of the kv_splits partial results: out = sum_s w_s O_s / sum_s w_s l_s, w_s = exp(m_s - max m)
 // (exp2 when the partials are in the log2 domain: bf16 path)
 template <typename T>
@@ -645,6 +661,19 @@ static void attn_launch_cfg(const AttnArgs& a_in, hipStream_t s) {
   const double flops = 4.0 * a.B * a.H * (double)a.Sq * a.Sk * HD * (a.causal ? 0.5 : 1.0);
   const double bytes = (double)a.B * a.H * HD * sizeof(T) * (2.0 * a.Sq + 2.0 * a.Sk);
   ProfScope prof(tag.c_str(), flops, bytes, s);
+  if constexpr (sizeof(T) == 2 && HD == 80 && NWV >= 8) {  // the SAM encoder's two attention forms
+    const int total = (int)(grid.x * grid.y * grid.z);
+    if (a.max_wg > 0 && a.kv_splits == 1 && total > a.max_wg) {
+      auto kw = &attn_walk_kernel<T, HD, NWV, BKVP, NRES>;
+      static bool attrw = false;
+      if (!attrw) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kw), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attrw = true;
+      }
+      hipLaunchKernelGGL(kw, dim3(a.max_wg), dim3(NWV * 64), lds, s, a, (int)grid.x, (int)grid.y, total);
+      return;
+    }
+  }
   hipLaunchKernelGGL((attn_kernel<T, HD, NWV, BKVP, NRES>), grid, dim3(NWV * 64), lds, s, a);
   if (a.kv_splits > 1) {
     const int64_t n = (int64_t)a.B * a.H * a.Sq * HD;

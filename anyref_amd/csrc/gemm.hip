@@ -312,7 +312,11 @@ __device__ __forceinline__ short8 fp8x8_to_bf16x8(uint2v r) {
   return o;
 }
 
-template <int BM, int BN, int WM, int WN, int NS, bool W8 = false>
+// PERSIST: the grid is CAPPED (GemmArgs::max_wg workgroups, a multiple of 8) and every workgroup walks the tiles
+// id, id + gridDim.x, ... one after the other -- the SAM encoder's launches on the side stream, which must leave
+// CUs to the decode GEMVs of the main stream (DESIGN.md "CU share of the side stream").  A separate instantiation:
+// the one-tile-per-workgroup kernels are untouched.
+template <int BM, int BN, int WM, int WN, int NS, bool W8 = false, bool PERSIST = false>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs a) {
   using T = bf16;
   constexpr int BK = 64, NW = WM * WN;
@@ -331,7 +335,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave / WN, wc = wave % WN;
   const int tiles_m = cdiv(a.M, BM), tiles_n = cdiv(a.N, BN), nwg = tiles_m * tiles_n;
-  int id = blockIdx.x;
+  for (int vb = blockIdx.x; vb < nwg; vb += gridDim.x) {  // (one pass unless PERSIST: see the end of the body)
+  int id = vb;
   if (a.order & 1) {
     const int q = nwg / 8, r = nwg % 8, xcd = id % 8;
     id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + id / 8;
@@ -534,6 +539,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs a) {
     });
   }
   gemm_epilogue<T, MI, NI>(a, acc, m0 + wr * TM, n0 + wc * TN, z, lane);
+  if constexpr (!PERSIST) break;
+  __syncthreads();  // every wave is done with this tile's LDS stages before the next tile's first DMA lands
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -897,6 +905,20 @@ void launch_gemm(const GemmArgs& a_in, hipStream_t s) {
         }
         ProfScope prof(tag, flops, bytes, s);
         dim3 grid(cdiv(a.N, BN) * cdiv(a.M, BM), 1, a.batch);
+        if constexpr (BM <= 256 && BM >= 128) {  // the SAM encoder's tiles
+          const int cap = a.max_wg / 8 * 8;
+          if (cap >= 8 && a.batch == 1 && (int)grid.x > cap) {
+            auto kp = &gemm_glds_kernel<BM, BN, WM, WN, NS, false, true>;
+            static bool attrp = false;
+            if (!attrp) {
+              HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kp), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)lds));
+              attrp = true;
+            }
+            hipLaunchKernelGGL(kp, dim3(cap), dim3(WM * WN * 64), lds, s, a);
+            return;
+          }
+        }
         hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, s, a);
       };
       using I1 = std::integral_constant<int, 1>;

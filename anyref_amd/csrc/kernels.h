@@ -131,6 +131,8 @@ struct GemmArgs {
   int w_fp8 = 0;
   const float* col_scale = nullptr;
   int group_m = 0;  // > 0 (set by the launcher): grouped tile order, this many tile rows per group
+  // > 0: at most this many workgroups (bf16 LDS-DMA kernel, M >= 128-row tiles, batch 1); each walks several tiles
+  int max_wg = 0;
   int vec_ok = 0;  // set by the launcher: N / strides / bases allow 4-wide vector epilogue accesses
   // optional: RMSNorm of the finished output rows fused into the split-K reduction (prefill o_proj /
   // down_proj -> the norm that follows).  Honoured only on the split-K path; *norm_done says whether it was.
@@ -240,6 +242,7 @@ struct AttnArgs {
   const void* rel_tab_w = nullptr;
   int rel_tab_ld = 0;
   int o_f32 = 0;  // 1: O is f32 instead of T (decode step feeds the f32 GEMV)
+  int max_wg = 0;  // > 0: at most this many workgroups (bf16, head dim 80, the SAM forms); each walks several blocks
   // set by the launcher: keys split over kv_splits workgroups per query block, partials merged afterwards
   int kv_splits = 1;
   float* part_o = nullptr;   // [splits][B][H][Sq][hd] un-normalised O

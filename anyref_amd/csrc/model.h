@@ -69,6 +69,12 @@ class ModelBase {
   void set_early_tail(bool on) { early_off_ = !on; }
   // hipGraph replay of the greedy decode step (default on)
   void set_graphs(bool on) { use_graphs_ = on; }
+  // workgroup cap of the encoder's GEMM / attention launches while it co-runs with the decode loop (0 = uncapped)
+  // `steps`: the decode steps the capped encoder is spread over (its blocks are queued ceil(depth / steps) per step)
+  void set_side_share(int wgs, int steps) {
+    side_wgs_ = wgs < 0 ? 0 : wgs;
+    if (steps > 0) side_steps_ = steps;
+  }
   bool early_off_ = getenv("ANYREF_NO_EARLY_TAIL") != nullptr;
   Profiler prof;
   Stamper stamp;  // kernel-side timestamps of the decode GEMVs (bench.py's in-situ roofline)
@@ -90,6 +96,9 @@ class ModelBase {
   bool finalized_ = false;
   bool overlap_ = true;
   bool use_graphs_ = true;
+  int side_wgs_ = getenv("ANYREF_SIDE_WGS") ? atoi(getenv("ANYREF_SIDE_WGS")) : 128;
+  int side_steps_ = getenv("ANYREF_SIDE_STEPS") ? atoi(getenv("ANYREF_SIDE_STEPS")) : 6;
+  int side_head_ = getenv("ANYREF_SIDE_HEAD") ? atoi(getenv("ANYREF_SIDE_HEAD")) : 3;  // encoder blocks queued beside CLIP
 };
 
 std::unique_ptr<ModelBase> make_model(const anyref_config& cfg, int device);

@@ -208,6 +208,7 @@ class Model : public ModelBase {
     }
     a.A = A; a.lda = lda; a.W = l.w; a.ldw = l.stride(); a.bias = l.b; a.C = C; a.ldc = ldc; a.M = M; a.N = l.n;
     a.K = l.k; a.act = act; a.c_f32 = c_f32 ? 1 : 0; a.resid = resid; a.ldr = ldr; a.row_map = row_map;
+    a.max_wg = cap_wg_;
     if (l.w8) {
       if (l.k % 64 == 0) {  // fp8 bytes straight into the GEMM (widened to bf16 per fragment, scale in the epilogue)
         a.W = l.w8; a.w_fp8 = 1; a.col_scale = l.ws;
@@ -304,10 +305,31 @@ class Model : public ModelBase {
   bool early_stop_ = false;  // a limit was hit: the tail decodes (or refuses) the rest
   // SAM image encoder on a second stream: it depends on nothing but the image, is MFMA-bound, and
   // overlaps the HBM-bound LLM decode (fork at the start of a call, join before the mask decoder).
-  void fork_sam(hipStream_t s, const float* sam_images, int B);
-  void fork_sam_head(hipStream_t s, const float* sam_images, int B);
-  int sam_head_blocks_ = getenv("ANYREF_SAM_HEAD_BLOCKS") ? atoi(getenv("ANYREF_SAM_HEAD_BLOCKS")) : 0;
-  bool sam_head_done_ = false;
+  // fed = true: only the fork point is set; the encoder's blocks are queued by sam_feed() as the decode loop advances
+  void fork_sam(hipStream_t s, const float* sam_images, int B, bool fed = false);
+  // CU share of the side stream (generate, batch 1).  A decode GEMV's throughput is proportional to the CUs it gets
+  // (21-24 GB/s per CU, with 192 CUs as with 256), and an encoder GEMM / attention launch holds all 256 with
+  // workgroups a GEMV workgroup cannot sit beside: uncapped, the two decode steps the encoder overlaps take 7.0 ms
+  // instead of 2.9 (kernel-side stamps).  So the encoder's GEMM / attention launches are capped at side_wgs_
+  // workgroups (ModelBase; 0 = uncapped), each walking several tiles, and the blocks are queued a few per decode
+  // step (sam_feed) instead of all at the fork: whatever is not queued when the loop ends (a short answer) runs
+  // uncapped, alone on the chip.  cap_wg_ is what the launch helpers read: non-zero only while sam_feed queues.
+  void sam_feed(int upto, bool capped);
+  int cap_wg_ = 0;
+  int sam_next_blk_ = 0;            // encoder blocks [0, sam_next_blk_) are queued on s2_
+  bool sam_enq_done_ = false;       // ... and so is the neck: ev_sam_ covers the whole encoder
+  const float* sam_img_ = nullptr;  // the call's images / batch (valid while sam_forked_)
+  int sam_B_ = 0;
+  struct PendingEarly {             // an early [SEG] mask that waits for the encoder to be queued in full
+    hipEvent_t ready;
+    int hidden_row;
+    const int32_t *resized_hw, *orig_hw;
+    float* out_masks;
+    int64_t cap;
+    float* out_low;
+  };
+  std::vector<PendingEarly> early_pending_;
+  void early_seg_run(const PendingEarly& e);
   hipStream_t s2_ = nullptr;
   hipEvent_t ev_fork_ = nullptr, ev_sam_ = nullptr;
   bool sam_forked_ = false;
@@ -986,23 +1008,40 @@ void Model<T>::finalize() {
 }
 
 template <typename T>
-void Model<T>::fork_sam(hipStream_t s, const float* sam_images, int B) {
+void Model<T>::fork_sam(hipStream_t s, const float* sam_images, int B, bool fed) {
   if (!overlap_) return;  // encoder then runs on `s` inside run_tail
   HIP_TRY(hipEventRecord(ev_fork_, s));
   HIP_TRY(hipStreamWaitEvent(s2_, ev_fork_, 0));
-  sam_encoder(s2_, sam_images, B, sam_emb_, sam_head_done_ ? sam_head_blocks_ : 0, -1);
-  HIP_TRY(hipEventRecord(ev_sam_, s2_));
   sam_forked_ = true;
-  sam_head_done_ = false;
+  sam_enq_done_ = false;
+  sam_next_blk_ = 0;
+  sam_img_ = sam_images;
+  sam_B_ = B;
+  early_pending_.clear();
+  if (!fed) sam_feed((int)sam_blocks_.size(), false);
 }
-// The first blocks of the encoder beside the CLIP tower (257 tokens: ~220 short launches that leave most CUs idle)
+// queue encoder blocks [sam_next_blk_, upto) on the side stream (block 0 brings the patch embedding, the last one the neck)
 template <typename T>
-void Model<T>::fork_sam_head(hipStream_t s, const float* sam_images, int B) {
-  if (!overlap_ || sam_head_blocks_ <= 0) return;
-  HIP_TRY(hipEventRecord(ev_fork_, s));
-  HIP_TRY(hipStreamWaitEvent(s2_, ev_fork_, 0));
-  sam_encoder(s2_, sam_images, B, sam_emb_, 0, sam_head_blocks_);
-  sam_head_done_ = true;
+void Model<T>::sam_feed(int upto, bool capped) {
+  const int nblk = (int)sam_blocks_.size();
+  if (!sam_forked_ || sam_enq_done_) return;
+  upto = std::min(upto, nblk);
+  if (upto <= sam_next_blk_) return;
+  cap_wg_ = capped ? side_wgs_ : 0;
+  try {
+    sam_encoder(s2_, sam_img_, sam_B_, sam_emb_, sam_next_blk_, upto);
+  } catch (...) {
+    cap_wg_ = 0;
+    throw;
+  }
+  cap_wg_ = 0;
+  sam_next_blk_ = upto;
+  if (upto == nblk) {
+    HIP_TRY(hipEventRecord(ev_sam_, s2_));
+    sam_enq_done_ = true;
+    for (const PendingEarly& e : early_pending_) early_seg_run(e);  // the masks that waited for the last block
+    early_pending_.clear();
+  }
 }
 
 template <typename T>
@@ -1323,6 +1362,7 @@ void Model<T>::sam_encoder(hipStream_t s, const float* images, int B, float* out
   for (int bi = blk0; bi < blk1; ++bi) {
     auto& L = sam_blocks_[bi];
     AttnArgs a;
+    a.max_wg = cap_wg_;
     a.q_hs = a.k_hs = a.v_hs = hd; a.o_hs = hd;
     a.q_rs = a.k_rs = a.v_rs = 3 * D; a.o_rs = D;
     a.H = nh; a.hd = hd; a.scale = 1.f / sqrtf((float)hd);
@@ -1575,9 +1615,10 @@ void Model<T>::join_sam(hipStream_t s) {
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
   }
+  if (sam_forked_ && !sam_enq_done_) HIP_TRY(hipEventRecord(ev_sam_, s2_));  // a call left half-way: wait for what was queued
   if (sam_forked_) HIP_TRY(hipStreamWaitEvent(s, ev_sam_, 0));  // everything after this on `s` sees the image embeddings
   sam_forked_ = false;
-  sam_head_done_ = false;
+  early_pending_.clear();
 }
 namespace {
 // generate / forward fork the encoder early; whatever path leaves them (a throw included) joins it
@@ -1601,23 +1642,33 @@ struct SamJoinGuard {
 template <typename T>
 void Model<T>::early_seg(hipEvent_t hidden_ready, int hidden_row, const int32_t* resized_hw, const int32_t* orig_hw,
                          float* out_masks, int64_t out_masks_cap, float* out_low) {
+  const PendingEarly e{hidden_ready, hidden_row, resized_hw, orig_hw, out_masks, out_masks_cap, out_low};
+  if (!sam_enq_done_) {  // blocks still to be fed: the mask is queued behind the last of them (sam_feed)
+    if ((int)early_pending_.size() + early_done_ >= cfg.max_seg) early_stop_ = true;
+    else early_pending_.push_back(e);
+    return;
+  }
+  early_seg_run(e);
+}
+template <typename T>
+void Model<T>::early_seg_run(const PendingEarly& e) {
   const anyref_config& c = cfg;
   const int H = c.llm_dim, slot = early_done_, L = 4 * sam_g_;
-  const int64_t hw = (int64_t)orig_hw[0] * orig_hw[1];
-  if (slot >= c.max_seg || (slot + 1) * hw > out_masks_cap) {  // run_tail refuses the call with the proper message
+  const int64_t hw = (int64_t)e.orig_hw[0] * e.orig_hw[1];
+  if (early_stop_ || slot >= c.max_seg || (slot + 1) * hw > e.cap) {  // run_tail refuses the call with the proper message
     early_stop_ = true;
     return;
   }
-  HIP_TRY(hipStreamWaitEvent(s2_, hidden_ready, 0));
-  HIP_TRY(hipMemcpyAsync(seg_h_ + (size_t)slot * H, hidden_all_ + (size_t)hidden_row * H, (size_t)H * 4,
+  HIP_TRY(hipStreamWaitEvent(s2_, e.ready, 0));
+  HIP_TRY(hipMemcpyAsync(seg_h_ + (size_t)slot * H, hidden_all_ + (size_t)e.hidden_row * H, (size_t)H * 4,
                          hipMemcpyDeviceToDevice, s2_));
   gemmf(s2_, seg_h_ + (size_t)slot * H, H, fc1_, seg_t_ + (size_t)slot * H, H, 1, ACT_RELU);
   gemmf(s2_, seg_t_ + (size_t)slot * H, H, fc2_, pred_emb_ + (size_t)slot * c.out_dim, c.out_dim, 1, ACT_NONE);
   mask_decoder(s2_, sam_emb_, pred_emb_ + (size_t)slot * c.out_dim, 1, nullptr, nullptr);
-  launch_postprocess(m_masks_, (int64_t)c.num_mask_tokens * L * L, 1, L, L, c.sam_img, resized_hw[0], resized_hw[1],
-                     orig_hw[0], orig_hw[1], out_masks + slot * hw, s2_);
-  if (out_low)
-    HIP_TRY(hipMemcpyAsync(out_low + (size_t)slot * L * L, m_masks_, (size_t)L * L * 4, hipMemcpyDeviceToDevice, s2_));
+  launch_postprocess(m_masks_, (int64_t)c.num_mask_tokens * L * L, 1, L, L, c.sam_img, e.resized_hw[0], e.resized_hw[1],
+                     e.orig_hw[0], e.orig_hw[1], e.out_masks + slot * hw, s2_);
+  if (e.out_low)
+    HIP_TRY(hipMemcpyAsync(e.out_low + (size_t)slot * L * L, m_masks_, (size_t)L * L * 4, hipMemcpyDeviceToDevice, s2_));
   HIP_TRY(hipEventRecord(ev_sam_, s2_));  // the join now waits for this mask too
   ++early_done_;
 }
@@ -1633,6 +1684,7 @@ void Model<T>::run_tail(hipStream_t s, const float* sam_images, int B, const std
   const int H = c.llm_dim, S = c.llm_max_seq, nseg = (int)seg_b.size();
   // join BEFORE anything below can throw: a refused call must not leave the encoder running on the side stream
   // over the caller's images, nor a stale "forked" flag for the next call
+  if (sam_forked_ && !sam_enq_done_) sam_feed((int)sam_blocks_.size(), false);  // (also flushes the pending early masks)
   const bool sam_ready = sam_forked_;
   const int done = early_done_;  // generate, batch 1: rows [0, done) were decoded by early_seg, masks and all
   early_done_ = 0;
@@ -1726,9 +1778,18 @@ void Model<T>::generate(hipStream_t s, const float* clip_images, const float* sa
   const int H = c.llm_dim, S = c.llm_max_seq, n_img = clip_n_;
   const bool keep_q = c.rephrase_weight > 0.f;
 
-  sam_head_done_ = false;
   SamJoinGuard<Model<T>> join_guard{this, s};
-  fork_sam_head(s, sam_images, B);
+  // Batch 1 with a CU share set: the encoder is fed to the side stream a few capped blocks at a time (fork_sam's
+  // note) -- the first ones beside the CLIP tower (257 tokens: ~170 launches of <= 96 workgroups that leave most CUs
+  // idle), none during prefill (MFMA-bound itself), the rest per decode step; larger batches bring more encoder work
+  // than the loop can hide at a reduced share: queued whole, uncapped, after prefill.
+  const int nblk = (int)sam_blocks_.size();
+  const bool fed = B == 1 && side_wgs_ > 0 && overlap_ && sizeof(T) == 2;
+  const int per_step = std::max(1, (nblk + side_steps_ - 1) / std::max(1, side_steps_));
+  if (fed) {
+    fork_sam(s, sam_images, B, true);
+    sam_feed(std::min(side_head_, nblk - 1), true);
+  }
   clip_tower(s, clip_images, B);
   std::vector<int> slen, img_pos;
   const int Sp = splice_inputs(s, input_ids, lens, B, Lmax, extra_embeds, extra_slots, n_extra, slen, img_pos);
@@ -1737,7 +1798,13 @@ void Model<T>::generate(hipStream_t s, const float* clip_images, const float* sa
   llm_prefill(s, B, Sp, slen_dev_, keep_q);
   // Fork the SAM encoder only now: CLIP + prefill are MFMA-bound themselves, the decode loop that
   // follows is HBM-bound and leaves the matrix cores to the encoder on the second stream.
-  fork_sam(s, sam_images, B);
+  if (fed) {  // the blocks behind the head ones wait for the end of prefill
+    HIP_TRY(hipEventRecord(ev_fork_, s));
+    HIP_TRY(hipStreamWaitEvent(s2_, ev_fork_, 0));
+    sam_feed(sam_next_blk_ + per_step, true);
+  } else {
+    fork_sam(s, sam_images, B);
+  }
   // first token: logits of the last prompt row of every sequence
   {
     stage_begin(ST_FIRST);
@@ -1779,7 +1846,10 @@ void Model<T>::generate(hipStream_t s, const float* clip_images, const float* sa
     const bool last = step == max_new_tokens - 1;
     HIP_TRY(hipMemcpyAsync(tok, next_dev_, B * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipEventRecord(ev_tok_[step & 1], s));
-    if (ahead && !last) decode_step_graph(s, B, keep_q);
+    if (ahead && !last) {
+      decode_step_graph(s, B, keep_q);
+      if (fed) sam_feed(sam_next_blk_ + per_step, true);  // the encoder's share of this step (host is idle until the token)
+    }
     HIP_TRY(hipEventSynchronize(ev_tok_[step & 1]));
     bool all = true;
     for (int b = 0; b < B; ++b) {
@@ -1793,8 +1863,12 @@ void Model<T>::generate(hipStream_t s, const float* clip_images, const float* sa
       all = all && fin[b];
     }
     if (all || last) break;
-    if (!ahead) decode_step_graph(s, B, keep_q);
+    if (!ahead) {
+      decode_step_graph(s, B, keep_q);
+      if (fed) sam_feed(sam_next_blk_ + per_step, true);
+    }
   }
+  if (fed) sam_feed(nblk, false);  // the loop is over: what is left of the encoder has the chip to itself
   const int Lout = Lmax + max_new_tokens;
   std::vector<int> seg_b, seg_pos, reph(B, 0);
   for (int b = 0; b < B; ++b) {
@@ -1835,7 +1909,6 @@ void Model<T>::forward_teacher(hipStream_t s, const float* clip_images, const fl
   if (B <= 0 || B > c.max_batch) throw std::runtime_error("batch exceeds max_batch");
   const int H = c.llm_dim, S = c.llm_max_seq, n_img = clip_n_;
   const bool keep_q = c.rephrase_weight > 0.f;
-  sam_head_done_ = false;
   early_done_ = 0;  // a generate() that threw between early_seg and run_tail must not leak its count into this call
   early_stop_ = false;
   SamJoinGuard<Model<T>> join_guard{this, s};

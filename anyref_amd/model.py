@@ -67,7 +67,7 @@ def _c_config(cfg: AnyRefConfig, mode: int, max_batch: int, max_seg: int) -> _li
 _NEEDS_HANDLE = frozenset({
     "generate", "model_forward_new", "forward", "__call__", "encode_images", "sam_encode", "mask_decode", "llm_forward",
     "seg_tail", "postprocess", "audio_encode", "device_bytes", "set_overlap", "set_early_tail", "set_graphs", "profile_enable", "profile_read",
-    "stamps_enable", "stamps_read"})
+    "stamps_enable", "stamps_read", "set_side_share"})
 
 
 class AnyRefForCausalLM:
@@ -342,6 +342,11 @@ class AnyRefForCausalLM:
     def set_graphs(self, on: bool):
         """hipGraph replay of the greedy decode step (default) or eager launches."""
         self._check(self.lib.anyref_set_graphs(self.h, int(on)), "set_graphs")
+
+    def set_side_share(self, wgs: int, steps: int = 0):
+        """Workgroup cap of the SAM encoder's GEMM / attention launches while it co-runs with the decode loop (0: none),
+        and the number of decode steps its blocks are spread over (0: keep)."""
+        self._check(self.lib.anyref_set_side_share(self.h, int(wgs), int(steps)), "set_side_share")
 
     # ---- per-kernel timing for bench.py ------------------------------------------------------
     def profile_enable(self, on: bool, only_tag: Optional[str] = None, sample_every: int = 1):

@@ -204,6 +204,14 @@ int anyref_set_early_tail(anyref_handle* h, int on);
  * them eagerly; the per-kernel profiler below always runs eagerly. */
 int anyref_set_graphs(anyref_handle* h, int on);
 
+/* CU share of the side stream (generate, batch 1; default 128 workgroups over 6 steps): while the SAM encoder co-runs
+ * with the decode loop, its GEMM / attention launches are capped at `wgs` workgroups (each walks several output
+ * tiles), so that the decode GEMVs -- whose throughput is proportional to the CUs they get -- keep CUs of their own
+ * instead of queueing behind 256 resident MFMA workgroups; the encoder's blocks are queued ceil(depth / steps) per
+ * decode step, and what is left when the loop ends runs uncapped.  wgs = 0: uncapped, queued whole at the fork
+ * (the behaviour for batches > 1).  steps <= 0 keeps the current value.  Results are bit-identical either way. */
+int anyref_set_side_share(anyref_handle* h, int wgs, int steps);
+
 /*
  * Per-kernel timing for the measurement harness (bench.py "roofline"): when enabled, every GEMM /
  * GEMV / attention launch is bracketed by a hipEvent pair on its launch stream.  After the caller
