@@ -80,6 +80,7 @@ SYMBOLS = {
     "anyref_stamps_collect": (_I, [_P, C.POINTER(_L)]),
     "anyref_stamps_read": (_I, [_P, _L, C.c_char_p, _I, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                C.POINTER(C.c_double), C.POINTER(_I)]),
+    "anyref_stamps_spread": (_I, [_P, _L, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "anyref_device_bytes": (_L, [_P]),
     "anyref_mode_name": (C.c_char_p, [_P]),
     # kernel-level test entry points (anyref_hip_ops.h)

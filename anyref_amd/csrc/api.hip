@@ -192,6 +192,15 @@ int anyref_stamps_read(anyref_handle* h, int64_t idx, char* name, int cap, doubl
   return 0;
 }
 
+int anyref_stamps_spread(anyref_handle* h, int64_t idx, double* start_spread_us, double* end_spread_us, double* wg_median_us) {
+  if (!h || idx < 0 || idx >= (int64_t)h->stamp_rows.size()) return -1;
+  const StampRow& r = h->stamp_rows[(size_t)idx];
+  *start_spread_us = r.start_spread_us;
+  *end_spread_us = r.end_spread_us;
+  *wg_median_us = r.wg_median_us;
+  return 0;
+}
+
 int64_t anyref_device_bytes(anyref_handle* h) { return h && h->m ? h->m->device_bytes() : 0; }
 
 const char* anyref_mode_name(anyref_handle* h) { return h && h->m ? h->m->mode_name() : ""; }

@@ -664,14 +664,35 @@ static void attn_launch_cfg(const AttnArgs& a_in, hipStream_t s) {
   if constexpr (sizeof(T) == 2 && HD == 80 && NWV >= 8) {  // the SAM encoder's two attention forms
     const int total = (int)(grid.x * grid.y * grid.z);
     if (a.max_wg > 0 && a.kv_splits == 1 && total > a.max_wg) {
-      auto kw = &attn_walk_kernel<T, HD, NWV, BKVP, NRES>;
-      static bool attrw = false;
-      if (!attrw) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kw), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attrw = true;
+      if constexpr (NRES > 0) {
+        // resident-key window form (13 waves = 128 VGPRs per wave: a walking loop around the body spills): the cap is
+        // kept by launching the windows in groups of max_wg / (query blocks x heads)
+        const int per = std::max(1, a.max_wg / (int)(grid.x * grid.y));
+        for (int b0 = 0; b0 < a.B; b0 += per) {
+          AttnArgs c = a;
+          c.B = std::min(per, a.B - b0);
+          c.Q = reinterpret_cast<const T*>(a.Q) + (int64_t)b0 * a.q_bs;
+          c.K = reinterpret_cast<const T*>(a.K) + (int64_t)b0 * a.k_bs;
+          c.V = reinterpret_cast<const T*>(a.V) + (int64_t)b0 * a.v_bs;
+          c.O = reinterpret_cast<T*>(a.O) + (int64_t)b0 * a.o_bs;
+          if (a.rel_p) c.rel_p = a.rel_p + (int64_t)b0 * a.Sq * a.rel_ld;
+          if (a.rel_h) c.rel_h = a.rel_h + (int64_t)b0 * a.H * a.Sq * a.kh;
+          if (a.rel_w) c.rel_w = a.rel_w + (int64_t)b0 * a.H * a.Sq * a.kw;
+          if (a.q_len) c.q_len = a.q_len + b0;
+          if (a.q_pos0) c.q_pos0 = a.q_pos0 + b0;
+          hipLaunchKernelGGL((attn_kernel<T, HD, NWV, BKVP, NRES>), dim3(grid.x, grid.y, c.B), dim3(NWV * 64), lds, s, c);
+        }
+        return;
+      } else {
+        auto kw = &attn_walk_kernel<T, HD, NWV, BKVP, NRES>;
+        static bool attrw = false;
+        if (!attrw) {
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kw), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+          attrw = true;
+        }
+        hipLaunchKernelGGL(kw, dim3(a.max_wg), dim3(NWV * 64), lds, s, a, (int)grid.x, (int)grid.y, total);
+        return;
       }
-      hipLaunchKernelGGL(kw, dim3(a.max_wg), dim3(NWV * 64), lds, s, a, (int)grid.x, (int)grid.y, total);
-      return;
     }
   }
   hipLaunchKernelGGL((attn_kernel<T, HD, NWV, BKVP, NRES>), grid, dim3(NWV * 64), lds, s, a);

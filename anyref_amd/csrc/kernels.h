@@ -72,6 +72,9 @@ struct StampRow {
   double bytes = 0;
   double t0_us = 0, t1_us = 0;  // relative to the first stamp collected
   int epoch = -1;               // replay index of the captured step, -1: eager launch
+  // spread over the launch's workgroups: last start - first start, last end - first end (the tail), and the median
+  // workgroup's own span
+  double start_spread_us = 0, end_spread_us = 0, wg_median_us = 0;
 };
 class Stamper {
  public:

@@ -179,17 +179,24 @@ std::vector<StampRow> Stamper::collect() {
   std::vector<unsigned long long> h(graph_off_ + graph_stride_ * (size_t)E);
   if (eager_used_) HIP_TRY(hipMemcpy(h.data(), buf_, eager_used_ * 8, hipMemcpyDeviceToHost));
   if (E) HIP_TRY(hipMemcpy(h.data() + graph_off_, buf_ + graph_off_, graph_stride_ * (size_t)E * 8, hipMemcpyDeviceToHost));
-  struct Raw { const Rec* r; unsigned long long t0, t1; int epoch; };
+  struct Raw { const Rec* r; unsigned long long t0, t1; int epoch; unsigned long long s1, e0; double med; };
   std::vector<Raw> raw;
   auto reduce = [&](const Rec& r, size_t base, int epoch) {
-    unsigned long long t0 = ~0ull, t1 = 0;
+    unsigned long long t0 = ~0ull, t1 = 0, s1 = 0, e0 = ~0ull;
+    std::vector<unsigned long long> spans;
     for (int g = 0; g < r.grid; ++g) {
       const unsigned long long a = h[base + (size_t)g * 2], b = h[base + (size_t)g * 2 + 1];
       if (a == 0 || b == 0) continue;  // a workgroup slot that was never written
       t0 = std::min(t0, a);
       t1 = std::max(t1, b);
+      s1 = std::max(s1, a);
+      e0 = std::min(e0, b);
+      spans.push_back(b - a);
     }
-    if (t1 > 0 && t0 != ~0ull) raw.push_back({&r, t0, t1, epoch});
+    if (t1 > 0 && t0 != ~0ull) {
+      std::sort(spans.begin(), spans.end());
+      raw.push_back({&r, t0, t1, epoch, s1, e0, (double)spans[spans.size() / 2] * 0.01});
+    }
   };
   for (const Rec& r : eager_) reduce(r, r.off, -1);
   for (int e = 0; e < E; ++e)
@@ -203,6 +210,9 @@ std::vector<StampRow> Stamper::collect() {
     row.t0_us = (double)(x.t0 - origin) * 0.01;  // 100 MHz wall clock
     row.t1_us = (double)(x.t1 - origin) * 0.01;
     row.epoch = x.epoch;
+    row.start_spread_us = (double)(x.s1 - x.t0) * 0.01;
+    row.end_spread_us = (double)(x.t1 - x.e0) * 0.01;
+    row.wg_median_us = x.med;
     rows.push_back(row);
   }
   // ready for the next pass: slots back to "never written", counters to zero

@@ -388,7 +388,10 @@ class AnyRefForCausalLM:
         for i in range(n.value):
             if self.lib.anyref_stamps_read(self.h, i, name, 128, C.byref(t0), C.byref(t1), C.byref(by), C.byref(ep)) != 0:
                 break
-            rows.append(dict(tag=name.value.decode(), t0_us=t0.value, t1_us=t1.value, bytes=by.value, epoch=ep.value))
+            a, b, c = C.c_double(), C.c_double(), C.c_double()
+            self.lib.anyref_stamps_spread(self.h, i, C.byref(a), C.byref(b), C.byref(c))
+            rows.append(dict(tag=name.value.decode(), t0_us=t0.value, t1_us=t1.value, bytes=by.value, epoch=ep.value,
+                             start_spread_us=a.value, end_spread_us=b.value, wg_median_us=c.value))
         return rows
 
     def postprocess(self, low: torch.Tensor, resized_size, original_size) -> torch.Tensor:

@@ -248,6 +248,10 @@ int anyref_stamps_enable(anyref_handle* h, int on);
 int anyref_stamps_collect(anyref_handle* h, int64_t* count);
 int anyref_stamps_read(anyref_handle* h, int64_t idx, char* name, int cap, double* t0_us, double* t1_us,
                        double* bytes, int* epoch);
+/* the same launch's spread over its workgroups: last start - first start (dispatch ramp), last end - first end (tail),
+ * and the median workgroup's own start-to-end span */
+int anyref_stamps_spread(anyref_handle* h, int64_t idx, double* start_spread_us, double* end_spread_us,
+                         double* wg_median_us);
 
 /* Bytes of HBM the handle holds (weights + workspaces), for sizing reports. */
 int64_t anyref_device_bytes(anyref_handle* h);

@@ -43,6 +43,44 @@ def _inputs(cfg, n, seed):
     return clip, sam, ids
 
 
+def _stage_attribution(cfg, sd, sd_cpu, clip, sam, ref0, img_emb, img_feats, sizes, H, W):
+    """Where does the bf16 mode's mask-logit error come from?  One stage at a time in bf16 (the perf handle), everything
+    else fp32 (the parity handle / the oracle's own intermediates), through the stage entry points of the C-ABI, on the
+    first prompt of the parity workload.  -> {stage: max-abs mask-logit error vs the oracle's masks}."""
+    from anyref_amd.model import AnyRefForCausalLM
+    full, hid_ref, mask_ref = ref0["output_ids"][0], ref0["hidden"][0], ref0["pred_masks"][0]
+    rows = (torch.where(O._is_seg(cfg, full[1:]))[0] + cfg.clip.n_patches - 1).tolist()
+    rows = [r for r in rows if r < hid_ref.shape[0]]
+    par = AnyRefForCausalLM.from_state_dict(cfg, sd, mode="parity", max_batch=1, max_seg=4)
+    perf = AnyRefForCausalLM.from_state_dict(cfg, sd, mode="perf", max_batch=1, max_seg=4)
+    perf.config.eos_token_id = None
+
+    def masks_err(emb_img, hidden_rows):
+        with torch.no_grad():
+            pred = O.text_hidden_fc(sd_cpu, hidden_rows.float().cpu())
+        m = par.mask_decode(emb_img[0], pred, sizes[0], (H[0], W[0]))["masks"]
+        return float((m.cpu() - mask_ref).abs().max())
+
+    def embeds(feats):
+        with torch.no_grad():
+            return O.splice_embeddings(sd_cpu, cfg, full[:-1], feats)[None]
+
+    out = {"range": float(mask_ref.abs().max())}
+    out["none (f32 stages on the oracle's intermediates)"] = masks_err(img_emb, hid_ref[rows])
+    out["SAM image encoder"] = masks_err(perf.sam_encode(sam).cpu(), hid_ref[rows])
+    feats_p = perf.encode_images(clip).cpu()[0]
+    out["CLIP tower + projector"] = masks_err(img_emb, par.llm_forward(embeds(feats_p))["hidden"][0][rows])
+    out["LLaMA (prefill kernels, teacher-forced)"] = masks_err(img_emb, perf.llm_forward(embeds(img_feats[0]))["hidden"][0][rows])
+    ids0 = full[: len(full) - T_NEW]
+    (oids, _, _), ex = perf.generate(clip, ids0[None], sam, sizes, H, W, max_new_tokens=T_NEW, _return_extras=True)
+    if oids[0].cpu().tolist() == full.tolist():
+        out["CLIP + LLaMA (generate: prefill + decode kernels)"] = masks_err(img_emb, ex["hidden"][0][rows])
+    del par, perf
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
+
+
 @pytest.mark.parametrize("init", ["fan_in", "normal"])
 def test_c2_full_size_parity_and_perf(init):
     from anyref_amd.model import AnyRefForCausalLM
@@ -90,6 +128,12 @@ def test_c2_full_size_parity_and_perf(init):
         gc.collect()
         torch.cuda.empty_cache()
     print(f"C2_FULL[{init}] " + json.dumps(report), flush=True)
+    if init == "fan_in":
+        att = _stage_attribution(cfg, sd, sd_cpu, clip, sam, refs[0], img_emb, img_feats, sizes, H, W)
+        print("C2_ERROR_BUDGET " + json.dumps(att), flush=True)
+        # each stage alone stays inside the end-to-end bound, and the f32 path on the oracle's intermediates inside 1e-3
+        assert att["none (f32 stages on the oracle's intermediates)"] <= 1e-3, att
+        assert all(v <= PERF_REL_BOUND[init] * att["range"] for k, v in att.items() if k != "range"), att
     p, q = report["parity"], report["perf"]
     # north_star, parity mode: identical greedy ids on every prompt, mask logits within 1e-3
     assert p["ids_match_rate"] == 1.0, p

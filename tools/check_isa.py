@@ -26,8 +26,8 @@ def asm_of(src, strict):
 def main():
     bad = 0
     allowed_scratch = ()
-    for src in ("gemm.hip", "attention.hip", "ops.hip"):
-        s = asm_of(src, strict=(src == "gemm.hip"))
+    for src in ("gemm.hip", "gemv.hip", "attention.hip", "ops.hip"):
+        s = asm_of(src, strict=src in ("gemm.hip", "gemv.hip"))
         for name, seg in re.findall(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)", s):
             if int(seg) > 0 and not any(a in name for a in allowed_scratch):
                 print(f"FAIL {src}: {name} uses {seg} bytes of scratch")
