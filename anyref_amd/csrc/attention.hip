@@ -185,6 +185,14 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const int bx, const
   bool rel_tab = false;  // tables given: bias computed here (resident form, bf16)
   if constexpr (NRES > 0 && BF) rel_tab = a.rel_tab_h != nullptr;
   const bool has_rel = a.rel_h != nullptr || a.rel_p != nullptr || rel_tab;
+  // Row-padded key order (resident form with rel-pos tables, kw <= 16: the SAM windows): LDS key slot 16 r + c holds
+  // key (r, c) of the kh x kw window (c >= kw: a zero row), so a 16-key block is exactly one bias row -- the kh term
+  // is ONE value per block, the kw term four registers per lane for the whole kernel, and the padding masks itself
+  // (bias -inf).  The general path below costs two LDS reads + a multiply-shift divide per score: with 13 waves on
+  // 4 SIMDs that VALU work, not the MFMAs, set the kernel's time (47.5 us per window layer).
+  bool rowpad = false;
+  if constexpr (NRES > 0 && BF && BKV % 16 == 0) rowpad = rel_tab && a.kw <= 16 && a.kh * 16 <= NRES * BKV;
+  if (rowpad) kv_end = a.kh * 16;
   T* Rs = reinterpret_cast<T*>(relw_s + BQ * a.kw);  // [2][32][LDK] zero-padded tables (rel_tab only)
   if constexpr (NRES > 0 && BF) {
     if (rel_tab) {
@@ -256,15 +264,29 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const int bx, const
   auto gload_tile = [&](int kt) {
 #pragma unroll
     for (int i = 0; i < KPT; ++i) {
-      const int v = tid + i * NT, row = v / KVEC, d = (v % KVEC) * VEC, j = kt + row;
-      kreg[i] = (v < BKV * KVEC && j < kv_end && d < HD) ? *reinterpret_cast<const uint4v*>(Kb + (int64_t)j * a.k_rs + d)
-                                                        : uint4v{0, 0, 0, 0};
+      const int v = tid + i * NT, row = v / KVEC, d = (v % KVEC) * VEC;
+      int j = kt + row;
+      bool ok = j < kv_end;
+      if (rowpad) {  // slot -> key (slot / 16, slot % 16) of the window
+        const int jr = j >> 4, jc = j & 15;
+        ok = jc < a.kw && jr < a.kh;
+        j = jr * a.kw + jc;
+      }
+      kreg[i] = (v < BKV * KVEC && ok && d < HD) ? *reinterpret_cast<const uint4v*>(Kb + (int64_t)j * a.k_rs + d)
+                                                 : uint4v{0, 0, 0, 0};
     }
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
-      const int v = tid + i * NT, row = v / VVEC, d = (v % VVEC) * VEC, j = kt + row;
-      vreg[i] = (v < BKV * VVEC && j < kv_end) ? *reinterpret_cast<const uint4v*>(Vb + (int64_t)j * a.v_rs + d)
-                                               : uint4v{0, 0, 0, 0};
+      const int v = tid + i * NT, row = v / VVEC, d = (v % VVEC) * VEC;
+      int j = kt + row;
+      bool ok = j < kv_end;
+      if (rowpad) {
+        const int jr = j >> 4, jc = j & 15;
+        ok = jc < a.kw && jr < a.kh;
+        j = jr * a.kw + jc;
+      }
+      vreg[i] = (v < BKV * VVEC && ok) ? *reinterpret_cast<const uint4v*>(Vb + (int64_t)j * a.v_rs + d)
+                                       : uint4v{0, 0, 0, 0};
     }
   };
   auto sstore_tile = [&](int slot = 0) {
@@ -347,6 +369,11 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const int bx, const
   } else {
     if (kv_end > kt_begin) gload_tile(kt_begin);
   }
+  float relw_pad[4] = {0.f, 0.f, 0.f, 0.f};  // rowpad: the kw term of this lane's four key columns (-inf: padding)
+  if (rowpad) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) relw_pad[r] = 4 * g + r < a.kw ? relw_s[il * a.kw + 4 * g + r] : -INFINITY;
+  }
   for (int kt = kt_begin; kt < kv_end; kt += BKV) {
     const int slot = NRES > 0 ? kt / BKV : 0;  // resident tile of this step
     const T* Kt = Ks + slot * BKV * LDK;
@@ -382,8 +409,20 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const int bx, const
       const float relh_tile = rel_fast ? relh_s[il * a.kh + kt / BKV] : 0.f;
       const float c1 = a.scale * bsc;
       // masking only where a tile can hold an invalid key for one of this wave's 16 queries (wave-uniform)
-      const bool need_mask = kt + BKV > kv_len || (a.causal && kt + BKV - 1 > pos0 + q0 + wave * 16);
-      if (need_mask) {
+      const bool need_mask = !rowpad && (kt + BKV > kv_len || (a.causal && kt + BKV - 1 > pos0 + q0 + wave * 16));
+      if (rowpad) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          const int jh = (kt >> 4) + nb;  // this key block = window row jh
+          const float bh = jh < a.kh ? relh_s[il * a.kh + jh] : -INFINITY;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float s = fmaf(st[nb][r], c1, bh + relw_pad[r]);
+            sv[nb][r] = s;
+            mx = fmaxf(mx, s);
+          }
+        }
+      } else if (need_mask) {
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
 #pragma unroll

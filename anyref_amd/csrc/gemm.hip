@@ -907,9 +907,9 @@ void launch_gemm(const GemmArgs& a_in, hipStream_t s) {
         if constexpr (BM <= 256 && BM >= 128) {  // the SAM encoder's tiles
           const int cap = a.max_wg / 8 * 8;
           if (cap >= 8 && a.batch == 1 && (int)grid.x > cap) {
-            if constexpr (BM == 256 && BN == 320) {
-              // this tile sits at the register limit (104 fragment + 160 accumulator registers): the walking loop
-              // spills, so the cap is kept by launching row blocks of at most `cap` tiles one after the other
+            if constexpr (BM == 256) {
+              // the 256-row tiles sit at the register limit (256 x 320: 104 fragment + 160 accumulator registers): the
+              // walking loop spills, so the cap is kept by launching row blocks of at most `cap` tiles one after the other
               const int tn = cdiv(a.N, BN), rows = std::max(1, cap / tn) * BM;
               for (int m0 = 0; m0 < a.M; m0 += rows) {
                 GemmArgs c = a;
