@@ -40,6 +40,21 @@ struct AMma<bf16> {
   static __device__ inline float fexp(float x) { return __expf(x); }
 };
 template <>
+struct AMma<f16> {
+  static constexpr int KS = 32, VEC = 8;
+  using Frag = short8;
+  static __device__ inline Frag lds(const f16* p, int lane) {
+    return *reinterpret_cast<const short8*>(p + 8 * (lane >> 4));
+  }
+  static __device__ inline Frag glb(const f16* row, int k0, int lane, bool ok, int HD) {
+    const int d = k0 + 8 * (lane >> 4);
+    if (ok && d < HD) return *reinterpret_cast<const short8*>(row + d);
+    return short8{0, 0, 0, 0, 0, 0, 0, 0};
+  }
+  static __device__ inline float4v mma(Frag a, Frag b, float4v c) { return mfma_16x16x32<f16>(a, b, c); }
+  static __device__ inline float fexp(float x) { return __expf(x); }
+};
+template <>
 struct AMma<float> {
   static constexpr int KS = 4, VEC = 4;
   using Frag = float;
@@ -513,11 +528,10 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const int bx, const
           uint2v vt[DB];
           lds_tr_blocks<DB>(vbase + (uint32_t)(nb * 16 * LDV * 2), vt);
           __builtin_amdgcn_sched_barrier(0);
-          const uint2v pb = uint2v{pack_bf16x2(sv[nb][0], sv[nb][1]), pack_bf16x2(sv[nb][2], sv[nb][3])};
+          const uint2v pb = uint2v{pack2_from_f32<T>(sv[nb][0], sv[nb][1]), pack2_from_f32<T>(sv[nb][2], sv[nb][3])};
 #pragma unroll
           for (int d = 0; d < DB; ++d)
-            ot[d] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(short4v, vt[d]),
-                                                              __builtin_bit_cast(short4v, pb), ot[d], 0, 0, 0);
+            ot[d] = mfma_16x16x16<T>(__builtin_bit_cast(short4v, vt[d]), __builtin_bit_cast(short4v, pb), ot[d]);
         }
       } else {
 #pragma unroll
@@ -560,10 +574,10 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const int bx, const
       if (a.o_f32) {
         Obf[c] = v[0]; Obf[c + 1] = v[1]; Obf[c + 2] = v[2]; Obf[c + 3] = v[3];
       } else if constexpr (BF) {
-        reinterpret_cast<uint16_t*>(Ob)[c] = f2bf(v[0]).x;
-        reinterpret_cast<uint16_t*>(Ob)[c + 1] = f2bf(v[1]).x;
-        reinterpret_cast<uint16_t*>(Ob)[c + 2] = f2bf(v[2]).x;
-        reinterpret_cast<uint16_t*>(Ob)[c + 3] = f2bf(v[3]).x;
+        reinterpret_cast<uint16_t*>(Ob)[c] = from_f32<T>(v[0]).x;
+        reinterpret_cast<uint16_t*>(Ob)[c + 1] = from_f32<T>(v[1]).x;
+        reinterpret_cast<uint16_t*>(Ob)[c + 2] = from_f32<T>(v[2]).x;
+        reinterpret_cast<uint16_t*>(Ob)[c + 3] = from_f32<T>(v[3]).x;
       } else {
         Ob[c] = v[0]; Ob[c + 1] = v[1]; Ob[c + 2] = v[2]; Ob[c + 3] = v[3];
       }
@@ -695,7 +709,8 @@ static void attn_launch_cfg(const AttnArgs& a_in, hipStream_t s) {
     a.part_ml = ws + rows * HD;
   }
   dim3 grid(cdiv(a.Sq, BQ) * a.kv_splits, a.H, a.B);
-  static const std::string tag = std::string(sizeof(T) == 2 ? "attn_bf16_hd" : "attn_f32_hd") + std::to_string(HD) +
+  static const std::string tag = std::string(is_half16<T>::value ? "attn_f16_hd" : sizeof(T) == 2 ? "attn_bf16_hd" : "attn_f32_hd") +
+                                 std::to_string(HD) +
                                  (NWV == 4 ? "" : "_w" + std::to_string(NWV)) + (NRES > 0 ? "_res" : "");
   const double flops = 4.0 * a.B * a.H * (double)a.Sq * a.Sk * HD * (a.causal ? 0.5 : 1.0);
   const double bytes = (double)a.B * a.H * HD * sizeof(T) * (2.0 * a.Sq + 2.0 * a.Sk);
@@ -798,6 +813,7 @@ void launch_attention(const AttnArgs& a, hipStream_t s) {
 }
 template void launch_attention<float>(const AttnArgs&, hipStream_t);
 template void launch_attention<bf16>(const AttnArgs&, hipStream_t);
+template void launch_attention<f16>(const AttnArgs&, hipStream_t);
 
 template <typename T, int HD>
 __global__ __launch_bounds__(512) void decode_attn_kernel(const float* __restrict__ qkv, const int* __restrict__ pos,

@@ -37,6 +37,27 @@ inline bf16 f2bf_host(float f) {  // RNE, host side (weight packing of small tab
   return r;
 }
 
+// IEEE half as raw 16-bit words: the storage type of the SAM image encoder in the perf build (3 more mantissa bits
+// than bf16 at the same MFMA rate and bytes; the reference itself runs the tower in fp16, eval_referseg.py:70-72).
+struct f16 {
+  uint16_t x;
+};
+__device__ inline float h2f(f16 h) { return (float)__builtin_bit_cast(_Float16, h.x); }
+__device__ inline f16 f2h(float f) {  // v_cvt_f16_f32, round to nearest even
+  f16 r;
+  r.x = __builtin_bit_cast(uint16_t, (_Float16)f);
+  return r;
+}
+// 16-bit storage types at a glance (what the MFMA wrappers and the traits below key on)
+template <typename T>
+struct is_half16 {
+  static constexpr bool value = false;
+};
+template <>
+struct is_half16<f16> {
+  static constexpr bool value = true;
+};
+
 template <typename T>
 __device__ inline float to_f32(T v);
 template <>
@@ -47,8 +68,16 @@ template <>
 __device__ inline float to_f32<bf16>(bf16 v) {
   return bf2f(v);
 }
+template <>
+__device__ inline float to_f32<f16>(f16 v) {
+  return h2f(v);
+}
 template <typename T>
 __device__ inline T from_f32(float v);
+template <>
+__device__ inline f16 from_f32<f16>(float v) {
+  return f2h(v);
+}
 template <>
 __device__ inline float from_f32<float>(float v) {
   return v;
@@ -69,6 +98,17 @@ template <>
 __device__ inline void store4_from_f32<bf16>(bf16* p, float a, float b, float c, float d) {
   typedef uint32_t u2 __attribute__((ext_vector_type(2)));
   *reinterpret_cast<u2*>(p) = u2{(uint32_t)f2bf(a).x | ((uint32_t)f2bf(b).x << 16), (uint32_t)f2bf(c).x | ((uint32_t)f2bf(d).x << 16)};
+}
+
+template <>
+__device__ inline void store4_from_f32<f16>(f16* p, float a, float b, float c, float d) {
+  typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+  *reinterpret_cast<u2*>(p) = u2{(uint32_t)f2h(a).x | ((uint32_t)f2h(b).x << 16), (uint32_t)f2h(c).x | ((uint32_t)f2h(d).x << 16)};
+}
+// two floats -> one packed pair of T (16-bit T)
+template <typename T>
+__device__ inline uint32_t pack2_from_f32(float lo, float hi) {
+  return (uint32_t)from_f32<T>(lo).x | ((uint32_t)from_f32<T>(hi).x << 16);
 }
 
 // ---- vector types --------------------------------------------------------------------------
@@ -94,6 +134,18 @@ struct Vec16<bf16> {
   }
 };
 template <>
+struct Vec16<f16> {
+  static constexpr int N = 8;
+  static __device__ inline void unpack(const uint4v& v, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t u = v[i];
+      f[2 * i] = (float)__builtin_bit_cast(_Float16, (uint16_t)(u & 0xffffu));
+      f[2 * i + 1] = (float)__builtin_bit_cast(_Float16, (uint16_t)(u >> 16));
+    }
+  }
+};
+template <>
 struct Vec16<float> {
   static constexpr int N = 4;
   static __device__ inline void unpack(const uint4v& v, float* f) {
@@ -104,6 +156,25 @@ struct Vec16<float> {
     }
   }
 };
+
+// ---- 16-bit MFMA by storage type (same rate, same fragment / accumulator maps for bf16 and f16) ----
+typedef __attribute__((ext_vector_type(4))) short short4v_;
+typedef __attribute__((ext_vector_type(8))) _Float16 half8v;
+typedef __attribute__((ext_vector_type(4))) _Float16 half4v;
+template <typename T>
+__device__ __forceinline__ float4v mfma_16x16x32(short8 a, short8 b, float4v c) {
+  if constexpr (is_half16<T>::value)
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8v, a), __builtin_bit_cast(half8v, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+template <typename T>
+__device__ __forceinline__ float4v mfma_16x16x16(short4v_ a, short4v_ b, float4v c) {
+  if constexpr (is_half16<T>::value)
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(half4v, a), __builtin_bit_cast(half4v, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+}
 
 // ---- fp8 (OCP e4m3fn on gfx950) weight-only quantisation helpers ------------------------------
 typedef float float2v __attribute__((ext_vector_type(2)));

@@ -14,6 +14,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include "model.h"
 
@@ -118,7 +119,12 @@ struct Affine {
   float* b = nullptr;
 };
 
-template <typename T>
+// T: storage type of the LLaMA / CLIP / audio operands (float: parity, bf16: perf).  TS: storage type of the SAM image
+// encoder's operands -- f16 in the perf build: per-stage attribution on the parity workload (tests/test_gpu_c2_full.py,
+// DESIGN.md §3) puts 3.8e-2 of the bf16 build's 3.7e-2 mask-logit error in this tower alone (CLIP 2.4e-3, LLaMA 8e-3);
+// f16 has 3 more mantissa bits at the same MFMA rate and bytes, and is what the reference runs it in
+// (eval_referseg.py:70-72).  ANYREF_SAM_BF16=1 builds the all-bf16 handle (A/B).
+template <typename T, typename TS = T>
 class Model : public ModelBase {
  public:
   Model(const anyref_config& c, int device) : ModelBase(c, device) {
@@ -146,7 +152,11 @@ class Model : public ModelBase {
     for (auto e : stage_ev_)
       if (e) (void)hipEventDestroy(e);
   }
-  const char* mode_name() const override { return sizeof(T) == 2 ? (fp8w_ ? "bf16+fp8w" : "bf16") : "f32"; }
+  const char* mode_name() const override {
+    return sizeof(T) == 2 ? (fp8w_ ? (is_half16<TS>::value ? "bf16+fp8w, SAM f16" : "bf16+fp8w")
+                                   : (is_half16<TS>::value ? "bf16, SAM f16" : "bf16"))
+                          : "f32";
+  }
   void finalize() override;
   void generate(hipStream_t s, const float* clip_images, const float* sam_images, const int64_t* input_ids,
                 const int32_t* lens, int B, int Lmax, const float* extra_embeds, const int32_t* extra_slots,
@@ -177,8 +187,10 @@ class Model : public ModelBase {
   float* own_f32(const std::string& name);  // take the raw f32 copy as is
   float* upload_f32(const std::vector<float>& v);
   std::vector<float> to_host(const std::string& name);
-  T* pack_rows(T* dst, int dst_row0, const std::string& name, int rows, int cols, int kpad);
-  Lin<T> pack_linear(const std::string& wname, const std::string& bname, int n, int k, int kalign = 8,
+  template <typename E>
+  E* pack_rows(E* dst, int dst_row0, const std::string& name, int rows, int cols, int kpad);
+  template <typename E = T>
+  Lin<E> pack_linear(const std::string& wname, const std::string& bname, int n, int k, int kalign = 8,
                      int rowpad = 0);
   LinF pack_linear_f32(const std::string& wname, const std::string& bname, int n, int k);
   Affine affine(const std::string& prefix, bool bias = true);
@@ -191,9 +203,10 @@ class Model : public ModelBase {
   // ---- op helpers ----
   // nrm / nrm_out: RMSNorm (gain nrm->g, llm eps) of the output rows written to nrm_out as T when the GEMM
   // takes its split-K path; returns whether that happened (else the caller runs the norm itself)
-  bool gemm(hipStream_t s, const T* A, int lda, const Lin<T>& l, void* C, int ldc, int M, int act, bool c_f32,
+  template <typename E>
+  bool gemm(hipStream_t s, const E* A, int lda, const Lin<E>& l, void* C, int ldc, int M, int act, bool c_f32,
             const float* resid = nullptr, int ldr = 0, const int* row_map = nullptr, const Affine* nrm = nullptr,
-            T* nrm_out = nullptr, bool swiglu = false, float ln_eps = -1.f) {
+            void* nrm_out = nullptr, bool swiglu = false, float ln_eps = -1.f) {  // nrm_out: E rows
     // nrm / nrm_out: the norm that follows (RMSNorm with the LLM's eps; LayerNorm with ln_eps when ln_eps >= 0) is
     // applied by the split-K reduction if the GEMM takes that path -- the return value says whether it did
     GemmArgs a;
@@ -209,15 +222,17 @@ class Model : public ModelBase {
     a.A = A; a.lda = lda; a.W = l.w; a.ldw = l.stride(); a.bias = l.b; a.C = C; a.ldc = ldc; a.M = M; a.N = l.n;
     a.K = l.k; a.act = act; a.c_f32 = c_f32 ? 1 : 0; a.resid = resid; a.ldr = ldr; a.row_map = row_map;
     a.max_wg = cap_wg_;
-    if (l.w8) {
-      if (l.k % 64 == 0) {  // fp8 bytes straight into the GEMM (widened to bf16 per fragment, scale in the epilogue)
-        a.W = l.w8; a.w_fp8 = 1; a.col_scale = l.ws;
-      } else {              // odd K: multiply a bf16 image of q * scale
-        launch_dequant_fp8_rows(l.w8, l.stride(), l.ws, l.n, l.k, deq_buf_, l.k, s);
-        a.W = deq_buf_; a.ldw = l.k;
+    if constexpr (std::is_same<E, T>::value) {
+      if (l.w8) {
+        if (l.k % 64 == 0) {  // fp8 bytes straight into the GEMM (widened to bf16 per fragment, scale in the epilogue)
+          a.W = l.w8; a.w_fp8 = 1; a.col_scale = l.ws;
+        } else {              // odd K: multiply a bf16 image of q * scale
+          launch_dequant_fp8_rows(l.w8, l.stride(), l.ws, l.n, l.k, deq_buf_, l.k, s);
+          a.W = deq_buf_; a.ldw = l.k;
+        }
       }
     }
-    launch_gemm<T>(a, s);
+    launch_gemm<E>(a, s);
     return fused;
   }
   // nn.Linear (or a row range of a fused one) as the weight operand of a decode GEMV
@@ -277,12 +292,13 @@ class Model : public ModelBase {
     a.K = l.k; a.act = act; a.c_f32 = 1; a.resid = resid; a.ldr = ldr;
     launch_gemm<float>(a, s);
   }
+  template <typename E = T>  // E: type of y when it is not f32
   void norm(hipStream_t s, const float* x, int ldx, const Affine& af, void* y, int ldy, int M, int D, float eps,
             bool y_f32, bool rms = false, const int* row_map = nullptr, int act = ACT_NONE) {
     NormArgs a;
     a.x = x; a.ldx = ldx; a.gain = af.g; a.bias = af.b; a.y = y; a.ldy = ldy; a.M = M; a.D = D; a.eps = eps;
     a.rms = rms ? 1 : 0; a.y_f32 = y_f32 ? 1 : 0; a.row_map = row_map; a.act = act;
-    launch_norm<T>(a, s);
+    launch_norm<E>(a, s);
   }
 
   // ---- stages ----
@@ -424,20 +440,20 @@ class Model : public ModelBase {
   // ---- SAM encoder ----
   struct SamBlock {
     Affine ln1, ln2;
-    Lin<T> qkv, proj, lin1, lin2;
-    Lin<T> rel;  // [2*Np, hd]: rows [0,2sz-1) = rel_pos_h, rows [Np, Np+2sz-1) = rel_pos_w, Np = 2*sz
+    Lin<TS> qkv, proj, lin1, lin2;
+    Lin<TS> rel;  // [2*Np, hd]: rows [0,2sz-1) = rel_pos_h, rows [Np, Np+2sz-1) = rel_pos_w, Np = 2*sz
     bool global = false;
   };
-  Lin<T> sam_patch_;
+  Lin<TS> sam_patch_;
   float* sam_pos_ = nullptr;
   std::vector<SamBlock> sam_blocks_;
-  Lin<T> neck0_, neck2_;
+  Lin<TS> neck0_, neck2_;
   Affine neck1_, neck3_;
   int sam_g_ = 0, sam_nw_ = 0, sam_wrows_ = 0;  // grid, windows per side, window-layout rows per image
   int *win2tok_ = nullptr, *tok2win_ = nullptr, *pad_rows_ = nullptr;  // pad_rows_: window-layout rows with no token
   int n_pad_rows_ = 0;                                                  // per image
-  T *s_col_ = nullptr, *s_hglob_ = nullptr, *s_qkv_ = nullptr, *s_att_ = nullptr,
-    *s_mlp_ = nullptr, *s_n1_ = nullptr, *s_col3_ = nullptr;
+  TS *s_col_ = nullptr, *s_hglob_ = nullptr, *s_qkv_ = nullptr, *s_att_ = nullptr,
+     *s_mlp_ = nullptr, *s_n1_ = nullptr, *s_col3_ = nullptr;
   float *s_x_ = nullptr, *s_relh_ = nullptr, *s_relw_ = nullptr, *s_n0_ = nullptr, *s_n2_ = nullptr,
         *sam_emb_ = nullptr;
 
@@ -466,45 +482,47 @@ class Model : public ModelBase {
 // ---------------------------------------------------------------------------------------------
 // packing
 // ---------------------------------------------------------------------------------------------
-template <typename T>
-float* Model<T>::own_f32(const std::string& name) {
+template <typename T, typename TS>
+float* Model<T, TS>::own_f32(const std::string& name) {
   auto it = raw_.find(name);
   if (it == raw_.end()) throw std::runtime_error("missing weight: " + name);
   float* p = it->second.p;
   it->second.p = nullptr;  // ownership moves to the packed model (still tracked in allocs_)
   return p;
 }
-template <typename T>
-std::vector<float> Model<T>::to_host(const std::string& name) {
+template <typename T, typename TS>
+std::vector<float> Model<T, TS>::to_host(const std::string& name) {
   const RawTensor& t = raw(name);
   std::vector<float> v((size_t)t.numel());
   HIP_TRY(hipMemcpy(v.data(), t.p, v.size() * 4, hipMemcpyDeviceToHost));
   return v;
 }
-template <typename T>
-float* Model<T>::upload_f32(const std::vector<float>& v) {
+template <typename T, typename TS>
+float* Model<T, TS>::upload_f32(const std::vector<float>& v) {
   float* p = talloc<float>(v.size());
   HIP_TRY(hipMemcpy(p, v.data(), v.size() * 4, hipMemcpyHostToDevice));
   return p;
 }
-template <typename T>
-T* Model<T>::pack_rows(T* dst, int dst_row0, const std::string& name, int rows, int cols, int kpad) {
+template <typename T, typename TS>
+template <typename E>
+E* Model<T, TS>::pack_rows(E* dst, int dst_row0, const std::string& name, int rows, int cols, int kpad) {
   const RawTensor& t = raw(name);
   if (t.numel() != (int64_t)rows * cols)
     throw std::runtime_error("shape mismatch for " + name + ": expected " + std::to_string(rows) + "x" +
                              std::to_string(cols) + ", got " + std::to_string(t.numel()) + " elements");
-  launch_convert<T>(t.p, cols, dst + (int64_t)dst_row0 * kpad, kpad, rows, cols, 0);
+  launch_convert<E>(t.p, cols, dst + (int64_t)dst_row0 * kpad, kpad, rows, cols, 0);
   return dst;
 }
-template <typename T>
-Lin<T> Model<T>::pack_linear(const std::string& wname, const std::string& bname, int n, int k, int kalign,
-                             int rowpad) {
-  Lin<T> l;
+template <typename T, typename TS>
+template <typename E>
+Lin<E> Model<T, TS>::pack_linear(const std::string& wname, const std::string& bname, int n, int k, int kalign,
+                                 int rowpad) {
+  Lin<E> l;
   l.n = n;
   l.k = round_up(k, kalign);
   l.ld = l.k + rowpad;
-  l.w = talloc<T>((size_t)n * l.ld);
-  if (l.ld != k) HIP_TRY(hipMemset(l.w, 0, (size_t)n * l.ld * sizeof(T)));
+  l.w = talloc<E>((size_t)n * l.ld);
+  if (l.ld != k) HIP_TRY(hipMemset(l.w, 0, (size_t)n * l.ld * sizeof(E)));
   pack_rows(l.w, 0, wname, n, k, l.ld);
   if (!bname.empty()) {
     if (raw(bname).numel() != n) throw std::runtime_error("bias shape mismatch for " + bname);
@@ -512,8 +530,8 @@ Lin<T> Model<T>::pack_linear(const std::string& wname, const std::string& bname,
   }
   return l;
 }
-template <typename T>
-LinF Model<T>::pack_linear_f32(const std::string& wname, const std::string& bname, int n, int k) {
+template <typename T, typename TS>
+LinF Model<T, TS>::pack_linear_f32(const std::string& wname, const std::string& bname, int n, int k) {
   LinF l;
   l.n = n;
   l.k = k;
@@ -523,8 +541,8 @@ LinF Model<T>::pack_linear_f32(const std::string& wname, const std::string& bnam
   if (!bname.empty()) l.b = own_f32(bname);
   return l;
 }
-template <typename T>
-Affine Model<T>::affine(const std::string& prefix, bool bias) {
+template <typename T, typename TS>
+Affine Model<T, TS>::affine(const std::string& prefix, bool bias) {
   Affine a;
   a.g = own_f32(prefix + ".weight");
   if (bias) a.b = own_f32(prefix + ".bias");
@@ -535,8 +553,8 @@ Affine Model<T>::affine(const std::string& prefix, bool bias) {
 // L with F.interpolate(mode="linear", align_corners=False) -- output row i at src = max((i + .5) * L / rows - .5, 0),
 // blending rows floor(src) and floor(src) + 1 (clamped) with (1 - frac, frac), in fp32 like ATen.  Input-independent,
 // so it is done on the host at finalize and the kernels only ever see (2*size-1)-row tables.
-template <typename T>
-void Model<T>::resample_rel_pos(const std::string& name, int rows, int hd) {
+template <typename T, typename TS>
+void Model<T, TS>::resample_rel_pos(const std::string& name, int rows, int hd) {
   const RawTensor& t = raw(name);
   if (t.shape.size() != 2 || t.shape[1] != hd || t.shape[0] < 1)
     throw std::runtime_error("rel_pos table " + name + " is not [L, head_dim]");
@@ -561,8 +579,8 @@ void Model<T>::resample_rel_pos(const std::string& name, int rows, int hd) {
 static const char* CLIP_P = "model.vision_tower.vision_tower.vision_model.";
 static const char* SAM_P = "model.visual_model.";
 
-template <typename T>
-void Model<T>::finalize() {
+template <typename T, typename TS>
+void Model<T, TS>::finalize() {
   HIP_TRY(hipSetDevice(device_));
   if (finalized_) return;
   const anyref_config& c = cfg;
@@ -749,7 +767,7 @@ void Model<T>::finalize() {
     sam_g_ = g;
     sam_nw_ = cdiv(g, ws);
     sam_wrows_ = sam_nw_ * sam_nw_ * ws * ws;
-    sam_patch_ = pack_linear(p + "patch_embed.proj.weight", p + "patch_embed.proj.bias", D, 3 * c.sam_patch * c.sam_patch);
+    sam_patch_ = pack_linear<TS>(p + "patch_embed.proj.weight", p + "patch_embed.proj.bias", D, 3 * c.sam_patch * c.sam_patch);
     if (raw(p + "pos_embed").numel() != (int64_t)g * g * D) throw std::runtime_error("pos_embed shape mismatch");
     sam_pos_ = own_f32(p + "pos_embed");
     sam_blocks_.resize(c.sam_depth);
@@ -760,10 +778,10 @@ void Model<T>::finalize() {
         if (c.sam_global_idx[j] == i) L.global = true;
       L.ln1 = affine(bp + "norm1");
       L.ln2 = affine(bp + "norm2");
-      L.qkv = pack_linear(bp + "attn.qkv.weight", bp + "attn.qkv.bias", 3 * D, D);
-      L.proj = pack_linear(bp + "attn.proj.weight", bp + "attn.proj.bias", D, D);
-      L.lin1 = pack_linear(bp + "mlp.lin1.weight", bp + "mlp.lin1.bias", c.sam_mlp_ratio * D, D);
-      L.lin2 = pack_linear(bp + "mlp.lin2.weight", bp + "mlp.lin2.bias", D, c.sam_mlp_ratio * D);
+      L.qkv = pack_linear<TS>(bp + "attn.qkv.weight", bp + "attn.qkv.bias", 3 * D, D);
+      L.proj = pack_linear<TS>(bp + "attn.proj.weight", bp + "attn.proj.bias", D, D);
+      L.lin1 = pack_linear<TS>(bp + "mlp.lin1.weight", bp + "mlp.lin1.bias", c.sam_mlp_ratio * D, D);
+      L.lin2 = pack_linear<TS>(bp + "mlp.lin2.weight", bp + "mlp.lin2.bias", D, c.sam_mlp_ratio * D);
       const int sz = L.global ? g : ws;
       // a table of another length (checkpoint trained at another window / image size) is resampled once, here
       resample_rel_pos(bp + "attn.rel_pos_h", 2 * sz - 1, hd);
@@ -774,12 +792,12 @@ void Model<T>::finalize() {
       const int kp = round_up(hd, 64) <= 3 * D - (nh_sam - 1) * hd ? round_up(hd, 64) : hd;
       L.rel.n = 2 * Np;
       L.rel.k = kp;
-      L.rel.w = talloc<T>((size_t)2 * Np * kp);
-      HIP_TRY(hipMemset(L.rel.w, 0, (size_t)2 * Np * kp * sizeof(T)));
+      L.rel.w = talloc<TS>((size_t)2 * Np * kp);
+      HIP_TRY(hipMemset(L.rel.w, 0, (size_t)2 * Np * kp * sizeof(TS)));
       pack_rows(L.rel.w, 0, bp + "attn.rel_pos_h", 2 * sz - 1, hd, kp);
       pack_rows(L.rel.w, Np, bp + "attn.rel_pos_w", 2 * sz - 1, hd, kp);
     }
-    neck0_ = pack_linear(p + "neck.0.weight", "", C, D);
+    neck0_ = pack_linear<TS>(p + "neck.0.weight", "", C, D);
     neck1_ = affine(p + "neck.1");
     neck3_ = affine(p + "neck.3");
     {  // 3x3 conv weight [O][C][3][3] -> [O][(ky*3+kx)*C + c]
@@ -791,8 +809,8 @@ void Model<T>::finalize() {
       float* rf = upload_f32(r);
       neck2_.n = C;
       neck2_.k = 9 * C;
-      neck2_.w = talloc<T>(r.size());
-      launch_convert<T>(rf, 9 * C, neck2_.w, 9 * C, C, 9 * C, 0);
+      neck2_.w = talloc<TS>(r.size());
+      launch_convert<TS>(rf, 9 * C, neck2_.w, 9 * C, C, 9 * C, 0);
       HIP_TRY(hipStreamSynchronize(0));
       dfree(rf);
     }
@@ -827,18 +845,18 @@ void Model<T>::finalize() {
     HIP_TRY(hipMemcpy(win2tok_, w2t.data(), w2t.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(tok2win_, t2w.data(), t2w.size() * 4, hipMemcpyHostToDevice));
     const size_t RT = (size_t)MB * g * g, RW = std::max((size_t)MB * sam_wrows_, RT);
-    s_col_ = talloc<T>(RT * sam_patch_.k);
+    s_col_ = talloc<TS>(RT * sam_patch_.k);
     s_x_ = talloc<float>(RT * D);
-    s_hglob_ = talloc<T>(RT * D);
-    s_qkv_ = talloc<T>(RW * 3 * D);
-    s_att_ = talloc<T>(RW * D);
-    s_mlp_ = talloc<T>(RT * c.sam_mlp_ratio * D);
+    s_hglob_ = talloc<TS>(RT * D);
+    s_qkv_ = talloc<TS>(RW * 3 * D);
+    s_att_ = talloc<TS>(RW * D);
+    s_mlp_ = talloc<TS>(RT * c.sam_mlp_ratio * D);
     const size_t rel_g = (size_t)MB * c.sam_heads * g * g * 4 * g;          // [H][B*g*g][2*Np], Np = 2g
     const size_t rel_w = (size_t)MB * sam_wrows_ * c.sam_heads * 4 * ws;     // [H][B*wrows][2*Np], Np = 2ws
     s_relh_ = talloc<float>(std::max(rel_g, rel_w));
     s_n0_ = talloc<float>(RT * C);
-    s_n1_ = talloc<T>(RT * C);
-    s_col3_ = talloc<T>(RT * 9 * C);
+    s_n1_ = talloc<TS>(RT * C);
+    s_col3_ = talloc<TS>(RT * 9 * C);
     s_n2_ = talloc<float>(RT * C);
     sam_emb_ = talloc<float>(RT * C);
   }
@@ -1007,8 +1025,8 @@ void Model<T>::finalize() {
   finalized_ = true;
 }
 
-template <typename T>
-void Model<T>::fork_sam(hipStream_t s, const float* sam_images, int B, bool fed) {
+template <typename T, typename TS>
+void Model<T, TS>::fork_sam(hipStream_t s, const float* sam_images, int B, bool fed) {
   if (!overlap_) return;  // encoder then runs on `s` inside run_tail
   HIP_TRY(hipEventRecord(ev_fork_, s));
   HIP_TRY(hipStreamWaitEvent(s2_, ev_fork_, 0));
@@ -1021,8 +1039,8 @@ void Model<T>::fork_sam(hipStream_t s, const float* sam_images, int B, bool fed)
   if (!fed) sam_feed((int)sam_blocks_.size(), false);
 }
 // queue encoder blocks [sam_next_blk_, upto) on the side stream (block 0 brings the patch embedding, the last one the neck)
-template <typename T>
-void Model<T>::sam_feed(int upto, bool capped) {
+template <typename T, typename TS>
+void Model<T, TS>::sam_feed(int upto, bool capped) {
   const int nblk = (int)sam_blocks_.size();
   if (!sam_forked_ || sam_enq_done_) return;
   upto = std::min(upto, nblk);
@@ -1044,8 +1062,8 @@ void Model<T>::sam_feed(int upto, bool capped) {
   }
 }
 
-template <typename T>
-void Model<T>::decode_step_graph(hipStream_t s, int B, bool keep_q) {
+template <typename T, typename TS>
+void Model<T, TS>::decode_step_graph(hipStream_t s, int B, bool keep_q) {
   if (!use_graphs_ || (g_prof && g_prof->on)) {  // the sampled profiler brackets kernels with events: eager
     llm_decode_step(s, B, keep_q);
     return;
@@ -1083,16 +1101,16 @@ void Model<T>::decode_step_graph(hipStream_t s, int B, bool keep_q) {
   if (stamped) stamp.graph_replayed(key);
 }
 
-template <typename T>
-void Model<T>::ensure_q_last() {
+template <typename T, typename TS>
+void Model<T, TS>::ensure_q_last() {
   if (!q_last_) q_last_ = talloc<T>((size_t)cfg.max_batch * cfg.llm_max_seq * cfg.llm_dim);
 }
 
 // ---------------------------------------------------------------------------------------------
 // CLIP tower + projector
 // ---------------------------------------------------------------------------------------------
-template <typename T>
-void Model<T>::clip_tower(hipStream_t s, const float* images, int B) {
+template <typename T, typename TS>
+void Model<T, TS>::clip_tower(hipStream_t s, const float* images, int B) {
   const anyref_config& c = cfg;
   const int Dc = c.clip_dim, n = clip_n_, S = n + 1, R = B * S, hd = Dc / c.clip_heads;
   launch_im2col_patch<T>(images, B, c.clip_image, c.clip_patch, c_col_, clip_kp_, s);
@@ -1126,8 +1144,8 @@ void Model<T>::clip_tower(hipStream_t s, const float* images, int B) {
   gemm(s, c_feat_, Dc, mm_proj_, img_feat_, c.llm_dim, B * n, ACT_NONE, true);
 }
 
-template <typename T>
-void Model<T>::encode_images(hipStream_t s, const float* clip_images, int B, float* out, float* clip_feat) {
+template <typename T, typename TS>
+void Model<T, TS>::encode_images(hipStream_t s, const float* clip_images, int B, float* out, float* clip_feat) {
   HIP_TRY(hipSetDevice(device_));
   if (B > cfg.max_batch) throw std::runtime_error("batch exceeds max_batch");
   clip_tower(s, clip_images, B);
@@ -1140,8 +1158,8 @@ void Model<T>::encode_images(hipStream_t s, const float* clip_images, int B, flo
 }
 
 // ImageBindModel.get_audio_feature (imagebind_model.py:477-511), the embedding half: see anyref_audio_encode
-template <typename T>
-void Model<T>::audio_encode(hipStream_t s, const float* mel, int n, float* emb) {
+template <typename T, typename TS>
+void Model<T, TS>::audio_encode(hipStream_t s, const float* mel, int n, float* emb) {
   HIP_TRY(hipSetDevice(device_));
   const anyref_config& c = cfg;
   if (aud_blocks_.empty()) throw std::runtime_error("this handle has no ImageBind audio trunk (aud_blocks = 0)");
@@ -1178,8 +1196,8 @@ void Model<T>::audio_encode(hipStream_t s, const float* mel, int n, float* emb) 
   launch_l2norm_scale(a_emb_, n, c.audio_dim, aud_scale_, emb, s);
 }
 
-template <typename T>
-void Model<T>::project_audio(hipStream_t s, const float* audio_emb, int n, float* out) {
+template <typename T, typename TS>
+void Model<T, TS>::project_audio(hipStream_t s, const float* audio_emb, int n, float* out) {
   HIP_TRY(hipSetDevice(device_));
   if (!has_audio_) throw std::runtime_error("model.audio_projector.* was not provided");
   if (n > cfg.max_batch * 64) throw std::runtime_error("too many audio rows");
@@ -1191,8 +1209,8 @@ void Model<T>::project_audio(hipStream_t s, const float* audio_emb, int n, float
 // ---------------------------------------------------------------------------------------------
 // LLaMA
 // ---------------------------------------------------------------------------------------------
-template <typename T>
-void Model<T>::llm_prefill(hipStream_t s, int B, int Sp, const int* lens_dev, bool keep_q) {
+template <typename T, typename TS>
+void Model<T, TS>::llm_prefill(hipStream_t s, int B, int Sp, const int* lens_dev, bool keep_q) {
   // l_x_ holds the spliced embeddings [B,Sp,H] (compact).  Fills the KV cache, hidden_all_[b, 0:Sp]
   // (post final norm) and next_dev_ (greedy token after each prompt).
   const anyref_config& c = cfg;
@@ -1237,8 +1255,8 @@ void Model<T>::llm_prefill(hipStream_t s, int B, int Sp, const int* lens_dev, bo
          true);
 }
 
-template <typename T>
-void Model<T>::llm_decode_step(hipStream_t s, int B, bool keep_q) {
+template <typename T, typename TS>
+void Model<T, TS>::llm_decode_step(hipStream_t s, int B, bool keep_q) {
   // next_dev_ -> embed -> all layers at pos_dev_ -> hidden_all_[b,pos] -> logits -> next_dev_; pos += 1
   const anyref_config& c = cfg;
   const int H = c.llm_dim, F = c.llm_mlp, nh = c.llm_heads, hd = H / nh, S = c.llm_max_seq, nl = c.llm_layers;
@@ -1307,8 +1325,8 @@ void Model<T>::llm_decode_step(hipStream_t s, int B, bool keep_q) {
                      rowmap_dev_, kvlen_dev_, s);
 }
 
-template <typename T>
-void Model<T>::llm_forward(hipStream_t s, const float* embeds, const int32_t* lens, int B, int Sn, float* hidden,
+template <typename T, typename TS>
+void Model<T, TS>::llm_forward(hipStream_t s, const float* embeds, const int32_t* lens, int B, int Sn, float* hidden,
                            float* logits, const int32_t* attn_q, float* attn_row) {
   HIP_TRY(hipSetDevice(device_));
   const anyref_config& c = cfg;
@@ -1342,8 +1360,8 @@ void Model<T>::llm_forward(hipStream_t s, const float* embeds, const int32_t* le
 // ---------------------------------------------------------------------------------------------
 // SAM image encoder
 // ---------------------------------------------------------------------------------------------
-template <typename T>
-void Model<T>::sam_encoder(hipStream_t s, const float* images, int B, float* out, int blk0, int blk1) {
+template <typename T, typename TS>
+void Model<T, TS>::sam_encoder(hipStream_t s, const float* images, int B, float* out, int blk0, int blk1) {
   const anyref_config& c = cfg;
   const int D = c.sam_dim, g = sam_g_, NT = g * g, RT = B * NT, ws = c.sam_window, nh = c.sam_heads, hd = D / nh;
   const int C = c.sam_out_chans, WR = sam_wrows_, nW = sam_nw_ * sam_nw_;
@@ -1351,13 +1369,13 @@ void Model<T>::sam_encoder(hipStream_t s, const float* images, int B, float* out
   const bool to_end = blk1 < 0 || blk1 >= nblk;
   if (to_end) blk1 = nblk;
   if (blk0 == 0) {
-    launch_im2col_patch<T>(images, B, c.sam_img, c.sam_patch, s_col_, sam_patch_.k, s);
+    launch_im2col_patch<TS>(images, B, c.sam_img, c.sam_patch, s_col_, sam_patch_.k, s);
     GemmArgs a;
     a.A = s_col_; a.lda = sam_patch_.k; a.W = sam_patch_.w; a.ldw = sam_patch_.k; a.bias = sam_patch_.b;
     a.C = s_x_; a.ldc = D; a.M = NT; a.N = D; a.K = sam_patch_.k; a.c_f32 = 1;
     a.resid = sam_pos_; a.ldr = D;  // + absolute position embedding, shared by every image
     a.batch = B; a.sA = (int64_t)NT * sam_patch_.k; a.sC = (int64_t)NT * D; a.sR = 0;
-    launch_gemm<T>(a, s);
+    launch_gemm<TS>(a, s);
   }
   for (int bi = blk0; bi < blk1; ++bi) {
     auto& L = sam_blocks_[bi];
@@ -1374,26 +1392,26 @@ void Model<T>::sam_encoder(hipStream_t s, const float* images, int B, float* out
       r.A = s_qkv_; r.lda = 3 * D; r.sA = hd; r.W = L.rel.w; r.ldw = L.rel.k; r.sW = 0;
       r.C = s_relh_; r.ldc = L.rel.n; r.sC = (int64_t)rows * L.rel.n; r.M = rows; r.N = L.rel.n; r.K = L.rel.k;
       r.c_f32 = 1; r.batch = nh;
-      launch_gemm<T>(r, s);
+      launch_gemm<TS>(r, s);
       a.rel_p = s_relh_; a.rel_ld = L.rel.n; a.rel_hs = (int64_t)rows * L.rel.n;
     };
     if (L.global) {
-      norm(s, s_x_, D, L.ln1, s_hglob_, D, RT, D, 1e-6f, false);
+      norm<TS>(s, s_x_, D, L.ln1, s_hglob_, D, RT, D, 1e-6f, false);
       gemm(s, s_hglob_, D, L.qkv, s_qkv_, 3 * D, RT, ACT_NONE, false);
       rel_gemm(RT);
       a.q_bs = a.k_bs = a.v_bs = (int64_t)NT * 3 * D; a.o_bs = (int64_t)NT * D;
       a.B = B; a.Sq = NT; a.Sk = NT; a.kh = g; a.kw = g;
-      launch_attention<T>(a, s);
+      launch_attention<TS>(a, s);
       gemm(s, s_att_, D, L.proj, s_x_, D, RT, ACT_NONE, true, s_x_, D);
     } else {
       const int RW = B * WR, S2 = ws * ws;
       // qkv over the REAL tokens only, scattered into the window layout by the GEMM epilogue; the pad rows of
       // a window (zero input after norm1, image_encoder.py:175-179) get exactly the bias.  16 % fewer GEMM
       // rows at SAM-H (4900 -> 4096 per image), which also makes the 256^2 tile fit (240 tiles).
-      norm(s, s_x_, D, L.ln1, s_hglob_, D, RT, D, 1e-6f, false);
+      norm<TS>(s, s_x_, D, L.ln1, s_hglob_, D, RT, D, 1e-6f, false);
       gemm(s, s_hglob_, D, L.qkv, s_qkv_, 3 * D, RT, ACT_NONE, false, nullptr, 0, tok2win_);
-      launch_fill_rows_bias<T>(s_qkv_, 3 * D, pad_rows_, n_pad_rows_ * B, L.qkv.b, 3 * D, s);
-      if (attention_takes_rel_tables((int)sizeof(T), hd, S2, S2, ws, ws)) {
+      launch_fill_rows_bias<TS>(s_qkv_, 3 * D, pad_rows_, n_pad_rows_ * B, L.qkv.b, 3 * D, s);
+      if (attention_takes_rel_tables((int)sizeof(TS), hd, S2, S2, ws, ws)) {
         // window bias straight from the tables inside the attention kernel (rows 0.. = rel_pos_h, Np.. = rel_pos_w)
         a.rel_tab_h = L.rel.w; a.rel_tab_w = L.rel.w + (size_t)(L.rel.n / 2) * L.rel.k; a.rel_tab_ld = L.rel.k;
       } else {
@@ -1401,26 +1419,26 @@ void Model<T>::sam_encoder(hipStream_t s, const float* images, int B, float* out
       }
       a.q_bs = a.k_bs = a.v_bs = (int64_t)S2 * 3 * D; a.o_bs = (int64_t)S2 * D;
       a.B = B * nW; a.Sq = S2; a.Sk = S2; a.kh = ws; a.kw = ws;
-      launch_attention<T>(a, s);
+      launch_attention<TS>(a, s);
       gemm(s, s_att_, D, L.proj, s_x_, D, RW, ACT_NONE, true, s_x_, D, win2tok_);
     }
-    norm(s, s_x_, D, L.ln2, s_hglob_, D, RT, D, 1e-6f, false);
+    norm<TS>(s, s_x_, D, L.ln2, s_hglob_, D, RT, D, 1e-6f, false);
     gemm(s, s_hglob_, D, L.lin1, s_mlp_, c.sam_mlp_ratio * D, RT, ACT_GELU, false);
     gemm(s, s_mlp_, c.sam_mlp_ratio * D, L.lin2, s_x_, D, RT, ACT_NONE, true, s_x_, D);
   }
   if (!to_end) return;
   // neck: 1x1 conv -> LN2d -> 3x3 conv -> LN2d (channels-last tokens; fp32 LayerNorm as the
   // reference forces under fp16, image_encoder.py:119-122)
-  launch_convert<T>(s_x_, D, s_hglob_, D, RT, D, s);
+  launch_convert<TS>(s_x_, D, s_hglob_, D, RT, D, s);
   gemm(s, s_hglob_, D, neck0_, s_n0_, C, RT, ACT_NONE, true);
-  norm(s, s_n0_, C, neck1_, s_n1_, C, RT, C, 1e-6f, false);
-  launch_im2col_3x3<T>(s_n1_, B, g, C, s_col3_, s);
+  norm<TS>(s, s_n0_, C, neck1_, s_n1_, C, RT, C, 1e-6f, false);
+  launch_im2col_3x3<TS>(s_n1_, B, g, C, s_col3_, s);
   gemm(s, s_col3_, 9 * C, neck2_, s_n2_, C, RT, ACT_NONE, true);
-  norm(s, s_n2_, C, neck3_, out, C, RT, C, 1e-6f, true);
+  norm<TS>(s, s_n2_, C, neck3_, out, C, RT, C, 1e-6f, true);
 }
 
-template <typename T>
-void Model<T>::sam_encode(hipStream_t s, const float* sam_images, int B, float* out) {
+template <typename T, typename TS>
+void Model<T, TS>::sam_encode(hipStream_t s, const float* sam_images, int B, float* out) {
   HIP_TRY(hipSetDevice(device_));
   if (B > cfg.max_batch) throw std::runtime_error("batch exceeds max_batch");
   sam_encoder(s, sam_images, B, out);
@@ -1429,8 +1447,8 @@ void Model<T>::sam_encode(hipStream_t s, const float* sam_images, int B, float* 
 // ---------------------------------------------------------------------------------------------
 // prompt encoder (text) + mask decoder, all f32
 // ---------------------------------------------------------------------------------------------
-template <typename T>
-void Model<T>::mask_decoder(hipStream_t s, const float* image_emb, const float* pred_emb, int n, float* masks4,
+template <typename T, typename TS>
+void Model<T, TS>::mask_decoder(hipStream_t s, const float* image_emb, const float* pred_emb, int n, float* masks4,
                             float* iou) {
   const anyref_config& c = cfg;
   const int C = c.sam_out_chans, g = sam_g_, NK = g * g, nt = c.num_mask_tokens, NQ = nt + 2, Ci = C / 2;
@@ -1537,8 +1555,8 @@ void Model<T>::mask_decoder(hipStream_t s, const float* image_emb, const float* 
   }
 }
 
-template <typename T>
-void Model<T>::mask_decode(hipStream_t s, const float* image_emb, const float* pred_emb, int n, float* masks4,
+template <typename T, typename TS>
+void Model<T, TS>::mask_decode(hipStream_t s, const float* image_emb, const float* pred_emb, int n, float* masks4,
                            float* iou, const int32_t* resized_hw, const int32_t* orig_hw, float* out_masks) {
   HIP_TRY(hipSetDevice(device_));
   if (n > cfg.max_seg) throw std::runtime_error("more prompts than max_seg");
@@ -1555,8 +1573,8 @@ void Model<T>::mask_decode(hipStream_t s, const float* image_emb, const float* p
 // ---------------------------------------------------------------------------------------------
 // generate / forward
 // ---------------------------------------------------------------------------------------------
-template <typename T>
-int Model<T>::splice_inputs(hipStream_t s, const int64_t* input_ids, const int32_t* lens, int B, int Lmax,
+template <typename T, typename TS>
+int Model<T, TS>::splice_inputs(hipStream_t s, const int64_t* input_ids, const int32_t* lens, int B, int Lmax,
                             const float* extra_embeds, const int32_t* extra_slots, int n_extra,
                             std::vector<int>& slen, std::vector<int>& img_pos) {
   const anyref_config& c = cfg;
@@ -1597,8 +1615,8 @@ int Model<T>::splice_inputs(hipStream_t s, const int64_t* input_ids, const int32
   return Sp;
 }
 
-template <typename T>
-void Model<T>::join_sam(hipStream_t s) {
+template <typename T, typename TS>
+void Model<T, TS>::join_sam(hipStream_t s) {
   static const bool timing = getenv("ANYREF_JOIN_TIMING") != nullptr;  // diagnostic: which stream the join waits for
   if (sam_forked_ && timing) {
     hipEvent_t e0, e1;
@@ -1639,8 +1657,8 @@ struct SamJoinGuard {
 // embedding is on the side stream anyway.  So its hand-off MLP, mask decoder and postprocess are queued on that stream
 // (behind the encoder) the moment the host sees the token, and run under the remaining decode steps instead of after
 // the loop (the reference always emits at least the EOS after a [SEG]; ~1 ms per image at batch 1).
-template <typename T>
-void Model<T>::early_seg(hipEvent_t hidden_ready, int hidden_row, const int32_t* resized_hw, const int32_t* orig_hw,
+template <typename T, typename TS>
+void Model<T, TS>::early_seg(hipEvent_t hidden_ready, int hidden_row, const int32_t* resized_hw, const int32_t* orig_hw,
                          float* out_masks, int64_t out_masks_cap, float* out_low) {
   const PendingEarly e{hidden_ready, hidden_row, resized_hw, orig_hw, out_masks, out_masks_cap, out_low};
   if (!sam_enq_done_) {  // blocks still to be fed: the mask is queued behind the last of them (sam_feed)
@@ -1650,8 +1668,8 @@ void Model<T>::early_seg(hipEvent_t hidden_ready, int hidden_row, const int32_t*
   }
   early_seg_run(e);
 }
-template <typename T>
-void Model<T>::early_seg_run(const PendingEarly& e) {
+template <typename T, typename TS>
+void Model<T, TS>::early_seg_run(const PendingEarly& e) {
   const anyref_config& c = cfg;
   const int H = c.llm_dim, slot = early_done_, L = 4 * sam_g_;
   const int64_t hw = (int64_t)e.orig_hw[0] * e.orig_hw[1];
@@ -1673,8 +1691,8 @@ void Model<T>::early_seg_run(const PendingEarly& e) {
   ++early_done_;
 }
 
-template <typename T>
-void Model<T>::run_tail(hipStream_t s, const float* sam_images, int B, const std::vector<int>& seg_b,
+template <typename T, typename TS>
+void Model<T, TS>::run_tail(hipStream_t s, const float* sam_images, int B, const std::vector<int>& seg_b,
                         const std::vector<int>& seg_pos, const std::vector<int>& reph_s, const int32_t* resized_hw,
                         const int32_t* orig_hw, int32_t* out_nseg, float* out_masks, int64_t out_masks_cap,
                         int64_t* mask_offsets, float* out_low, const float* attn_given, int attn_n) {
@@ -1764,8 +1782,8 @@ void Model<T>::run_tail(hipStream_t s, const float* sam_images, int B, const std
   }
 }
 
-template <typename T>
-void Model<T>::generate(hipStream_t s, const float* clip_images, const float* sam_images, const int64_t* input_ids,
+template <typename T, typename TS>
+void Model<T, TS>::generate(hipStream_t s, const float* clip_images, const float* sam_images, const int64_t* input_ids,
                         const int32_t* lens, int B, int Lmax, const float* extra_embeds, const int32_t* extra_slots,
                         int n_extra, const int32_t* resized_hw, const int32_t* orig_hw, int max_new_tokens,
                         int eos_token_id, int64_t* out_ids, int32_t* out_lens, int32_t* out_nseg, float* out_masks,
@@ -1778,7 +1796,7 @@ void Model<T>::generate(hipStream_t s, const float* clip_images, const float* sa
   const int H = c.llm_dim, S = c.llm_max_seq, n_img = clip_n_;
   const bool keep_q = c.rephrase_weight > 0.f;
 
-  SamJoinGuard<Model<T>> join_guard{this, s};
+  SamJoinGuard<Model<T, TS>> join_guard{this, s};
   // Batch 1 with a CU share set: the encoder is fed to the side stream a few capped blocks at a time (fork_sam's
   // note) -- the first ones beside the CLIP tower (257 tokens: ~170 launches of <= 96 workgroups that leave most CUs
   // idle), none during prefill (MFMA-bound itself), the rest per decode step; larger batches bring more encoder work
@@ -1896,8 +1914,8 @@ void Model<T>::generate(hipStream_t s, const float* clip_images, const float* sa
     HIP_TRY(hipMemcpyAsync(out_hidden, hidden_all_, (size_t)B * S * H * 4, hipMemcpyDeviceToDevice, s));
 }
 
-template <typename T>
-void Model<T>::forward_teacher(hipStream_t s, const float* clip_images, const float* sam_images,
+template <typename T, typename TS>
+void Model<T, TS>::forward_teacher(hipStream_t s, const float* clip_images, const float* sam_images,
                                const int64_t* input_ids, const int32_t* lens, int B, int Lmax,
                                const float* extra_embeds, const int32_t* extra_slots, int n_extra,
                                const int32_t* rephrase_start, const int32_t* resized_hw, const int32_t* orig_hw,
@@ -1911,7 +1929,7 @@ void Model<T>::forward_teacher(hipStream_t s, const float* clip_images, const fl
   const bool keep_q = c.rephrase_weight > 0.f;
   early_done_ = 0;  // a generate() that threw between early_seg and run_tail must not leak its count into this call
   early_stop_ = false;
-  SamJoinGuard<Model<T>> join_guard{this, s};
+  SamJoinGuard<Model<T, TS>> join_guard{this, s};
   fork_sam(s, sam_images, B);
   clip_tower(s, clip_images, B);
   std::vector<int> slen, img_pos;
@@ -1942,8 +1960,8 @@ void Model<T>::forward_teacher(hipStream_t s, const float* clip_images, const fl
     HIP_TRY(hipMemcpyAsync(out_hidden, hidden_all_, (size_t)B * S * H * 4, hipMemcpyDeviceToDevice, s));
 }
 
-template <typename T>
-void Model<T>::seg_tail(hipStream_t s, const float* sam_images, const int64_t* ids, const int32_t* ids_lens,
+template <typename T, typename TS>
+void Model<T, TS>::seg_tail(hipStream_t s, const float* sam_images, const int64_t* ids, const int32_t* ids_lens,
                         const int32_t* ref_pos, int B, int Lmax, int teacher, const float* hidden, int hidden_rows,
                         const float* attn_mean, const int32_t* resized_hw, const int32_t* orig_hw, int32_t* out_nseg,
                         float* out_masks, int64_t out_masks_cap, int64_t* mask_offsets, float* out_low) {
@@ -1982,8 +2000,11 @@ void Model<T>::seg_tail(hipStream_t s, const float* sam_images, const int64_t* i
 
 std::unique_ptr<ModelBase> make_model(const anyref_config& cfg, int device) {
   if (cfg.mode == ANYREF_MODE_PARITY) return std::unique_ptr<ModelBase>(new Model<float>(cfg, device));
-  if (cfg.mode == ANYREF_MODE_PERF || cfg.mode == ANYREF_MODE_PERF_FP8W)
-    return std::unique_ptr<ModelBase>(new Model<bf16>(cfg, device));
+  if (cfg.mode == ANYREF_MODE_PERF || cfg.mode == ANYREF_MODE_PERF_FP8W) {
+    static const bool sam_bf16 = getenv("ANYREF_SAM_BF16") != nullptr;  // A/B: the all-bf16 handle of rounds 1-2
+    if (sam_bf16) return std::unique_ptr<ModelBase>(new Model<bf16, bf16>(cfg, device));
+    return std::unique_ptr<ModelBase>(new Model<bf16, f16>(cfg, device));
+  }
   throw std::runtime_error("unknown mode");
 }
 

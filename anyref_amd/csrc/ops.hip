@@ -370,6 +370,7 @@ void launch_norm(const NormArgs& a, hipStream_t s) {
 }
 template void launch_norm<float>(const NormArgs&, hipStream_t);
 template void launch_norm<bf16>(const NormArgs&, hipStream_t);
+template void launch_norm<f16>(const NormArgs&, hipStream_t);
 
 // ---------------------------------------------------------------------------------------------
 // im2col
@@ -403,6 +404,7 @@ void launch_im2col_patch(const float* img, int B, int S, int p, void* out, int K
 }
 template void launch_im2col_patch<float>(const float*, int, int, int, void*, int, hipStream_t);
 template void launch_im2col_patch<bf16>(const float*, int, int, int, void*, int, hipStream_t);
+template void launch_im2col_patch<f16>(const float*, int, int, int, void*, int, hipStream_t);
 
 template <typename T>
 __global__ void im2col_3x3_kernel(const T* __restrict__ in, int B, int g, int C, T* __restrict__ out) {
@@ -429,6 +431,7 @@ void launch_im2col_3x3(const void* in, int B, int g, int C, void* out, hipStream
 }
 template void launch_im2col_3x3<float>(const void*, int, int, int, void*, hipStream_t);
 template void launch_im2col_3x3<bf16>(const void*, int, int, int, void*, hipStream_t);
+template void launch_im2col_3x3<f16>(const void*, int, int, int, void*, hipStream_t);
 
 // ---------------------------------------------------------------------------------------------
 // converts / adds
@@ -454,6 +457,7 @@ void launch_convert(const float* in, int64_t ld_in, void* out, int64_t ld_out, i
 }
 template void launch_convert<float>(const float*, int64_t, void*, int64_t, int, int, hipStream_t);
 template void launch_convert<bf16>(const float*, int64_t, void*, int64_t, int, int, hipStream_t);
+template void launch_convert<f16>(const float*, int64_t, void*, int64_t, int, int, hipStream_t);
 
 template <typename T>
 __global__ void add_rows_kernel(const float* __restrict__ a, const float* __restrict__ b, int bmod,
@@ -1445,6 +1449,7 @@ void launch_fill_rows_bias(void* dst, int ld, const int* rows, int nrows, const 
 }
 template void launch_fill_rows_bias<float>(void*, int, const int*, int, const float*, int, hipStream_t);
 template void launch_fill_rows_bias<bf16>(void*, int, const int*, int, const float*, int, hipStream_t);
+template void launch_fill_rows_bias<f16>(void*, int, const int*, int, const float*, int, hipStream_t);
 
 // ---------------------------------------------------------------------------------------------
 // fp8 weight-only quantisation (BASELINE config 5: 13B LLM, fp8 weights).  One workgroup per row.

@@ -33,7 +33,9 @@ int anyref_op_gemm(int t, void* stream, const void* A, const void* W, const floa
     a.A = A; a.lda = K; a.W = W; a.ldw = K; a.bias = bias; a.C = C; a.ldc = N; a.resid = resid; a.ldr = N;
     a.row_map = row_map; a.M = M; a.N = N; a.K = K; a.act = act; a.c_f32 = c_f32;
     if (const char* e = getenv("ANYREF_OPTEST_LDW_PAD")) a.ldw = K + atoi(e);  // probe: padded weight rows
-    if (t == 0) launch_gemm<float>(a, (hipStream_t)stream); else launch_gemm<bf16>(a, (hipStream_t)stream);
+    if (t == 0) launch_gemm<float>(a, (hipStream_t)stream);
+    else if (t == 2) launch_gemm<f16>(a, (hipStream_t)stream);
+    else launch_gemm<bf16>(a, (hipStream_t)stream);
   });
 }
 
@@ -54,7 +56,9 @@ int anyref_op_norm(int t, void* stream, const float* x, const float* gain, const
     NormArgs a;
     a.x = x; a.ldx = D; a.gain = gain; a.bias = bias; a.y = y; a.ldy = D; a.M = M; a.D = D; a.eps = eps;
     a.rms = rms; a.y_f32 = 1;
-    if (t == 0) launch_norm<float>(a, (hipStream_t)stream); else launch_norm<bf16>(a, (hipStream_t)stream);
+    if (t == 0) launch_norm<float>(a, (hipStream_t)stream);
+    else if (t == 2) launch_norm<f16>(a, (hipStream_t)stream);
+    else launch_norm<bf16>(a, (hipStream_t)stream);
   });
 }
 
@@ -69,11 +73,13 @@ int anyref_op_attention(int t, void* stream, const void* q, const void* k, const
     a.o_bs = (int64_t)Sq * H * hd; a.o_rs = H * hd; a.o_hs = hd;
     a.B = B; a.H = H; a.Sq = Sq; a.Sk = Sk; a.hd = hd; a.scale = scale; a.causal = causal; a.kv_len = kv_len;
     a.rel_h = rel_h; a.rel_w = rel_w; a.kh = kh; a.kw = kw;
-    if (t == 0) launch_attention<float>(a, (hipStream_t)stream); else launch_attention<bf16>(a, (hipStream_t)stream);
+    if (t == 0) launch_attention<float>(a, (hipStream_t)stream);
+    else if (t == 2) launch_attention<f16>(a, (hipStream_t)stream);
+    else launch_attention<bf16>(a, (hipStream_t)stream);
   });
 }
 
-int anyref_op_attention_tab(void* stream, const void* q, const void* k, const void* v, void* o, int B, int H, int S,
+int anyref_op_attention_tab(int t, void* stream, const void* q, const void* k, const void* v, void* o, int B, int H, int S,
                             int hd, float scale, const void* tab_h, const void* tab_w, int tab_ld, int kh, int kw) {
   OP_GUARD({
     AttnArgs a;
@@ -82,7 +88,8 @@ int anyref_op_attention_tab(void* stream, const void* q, const void* k, const vo
     a.q_rs = a.k_rs = a.v_rs = a.o_rs = H * hd; a.q_hs = a.k_hs = a.v_hs = a.o_hs = hd;
     a.B = B; a.H = H; a.Sq = S; a.Sk = S; a.hd = hd; a.scale = scale;
     a.rel_tab_h = tab_h; a.rel_tab_w = tab_w; a.rel_tab_ld = tab_ld; a.kh = kh; a.kw = kw;
-    launch_attention<bf16>(a, (hipStream_t)stream);
+    if (t == 2) launch_attention<f16>(a, (hipStream_t)stream);
+    else launch_attention<bf16>(a, (hipStream_t)stream);
   });
 }
 

@@ -2,7 +2,8 @@
  * anyref_hip_ops.h — kernel-level entry points of libanyref_hip.so used by the parity tests
  * (tests/test_gpu_ops.py) to check every hand-written kernel against the oracle / torch fp32 in
  * isolation.  Not part of the drop-in boundary (that is anyref_hip.h).
- * `t` selects the storage type: 0 = f32 (MFMA 16x16x4 f32), 1 = bf16 (MFMA 16x16x32 bf16).
+ * `t` selects the storage type: 0 = f32 (MFMA 16x16x4 f32), 1 = bf16 (MFMA 16x16x32 bf16), 2 = f16 (MFMA 16x16x32
+ * f16: the SAM image encoder of the perf build; GEMM, norm and attention entries).
  * All pointers are device pointers; `stream` is a hipStream_t.
  */
 #ifndef ANYREF_HIP_OPS_H
@@ -83,11 +84,11 @@ int anyref_op_clip_finish(void* stream, const uint8_t* img, int ih, int iw, int 
 int anyref_op_kaldi_fbank(void* stream, const float* wave, int C, int T, int win, int shift, int padded, float preemph,
                           const float* banks, int n_mel, const double* tw, double* scratch, int target_len, float mean,
                           float stdv, float* out);
-/* bf16 window attention with the decomposed rel-pos bias computed inside the kernel from the tables
- * (image_encoder.py:321-392 get_rel_pos / add_decomposed_rel_pos): tab_h bf16 [2*kh-1, hd], tab_w bf16 [2*kw-1, hd],
+/* 16-bit (t = 1 bf16 / 2 f16) window attention with the decomposed rel-pos bias computed inside the kernel from the tables
+ * (image_encoder.py:321-392 get_rel_pos / add_decomposed_rel_pos): tab_h [2*kh-1, hd], tab_w [2*kw-1, hd] in type t,
  * rows at stride tab_ld elements; S = kh*kw tokens, [B,S,H,hd] operands.  Only the shapes the resident-key form
  * takes (hd 80, 192 < S <= 208); others are refused. */
-int anyref_op_attention_tab(void* stream, const void* q, const void* k, const void* v, void* o, int B, int H, int S,
+int anyref_op_attention_tab(int t, void* stream, const void* q, const void* k, const void* v, void* o, int B, int H, int S,
                             int hd, float scale, const void* tab_h, const void* tab_w, int tab_ld, int kh, int kw);
 /* Sam.postprocess_masks on low [n,lh,lw] f32 */
 int anyref_op_postprocess(void* stream, const float* low, int n, int lh, int lw, int S, int rh, int rw, int H,

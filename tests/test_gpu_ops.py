@@ -12,7 +12,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-TOL = {0: 2e-5, 1: 2e-2}
+TOL = {0: 2e-5, 1: 2e-2, 2: 3e-3}
 
 
 @pytest.fixture(scope="module")
@@ -21,14 +21,16 @@ def lib():
     return _lib.load()
 
 
+_DT = {0: torch.float32, 1: torch.bfloat16, 2: torch.float16}     # ty: storage type id of include/anyref_hip_ops.h
+
+
 def dev(t, ty):
-    t = t.cuda()
-    return t.to(torch.bfloat16).contiguous() if ty == 1 else t.float().contiguous()
+    return t.cuda().to(_DT[ty]).contiguous()
 
 
 def rnd(t, ty):
     """what the kernel sees after storage rounding"""
-    return t.to(torch.bfloat16).float() if ty == 1 else t
+    return t.to(_DT[ty]).float()
 
 
 _KEEP = []
@@ -56,7 +58,7 @@ def close(got, ref, tol):
     assert math.isfinite(err) and err <= tol * scale, f"max abs err {err:.3e} vs scale {scale:.3e} (tol {tol})"
 
 
-@pytest.mark.parametrize("ty", [0, 1])
+@pytest.mark.parametrize("ty", [0, 1, 2])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (257, 192, 192), (320, 384, 1032), (6, 256, 256), (1000, 64, 72),
                                    (70, 130, 24), (4900, 200, 1280), (320, 640, 4096), (64, 128, 128)])
 @pytest.mark.parametrize("act", [0, 1, 2, 3, 4])
@@ -83,17 +85,19 @@ def test_gemm(lib, ty, M, N, K, act):
                                    (8, 15360, 5120), (8, 5120, 13824), (2560, 15360, 128)])
 def test_gemm_tile_paths_of_the_big_shapes(lib, M, N, K):
     """the tile heuristics of launch_gemm at the SAM-H / LLaMA-7B output shapes (short K): 256^2, 256x320,
-    128x160 (ragged LDS-DMA round, 1 .. 7 K tiles through the 3-stage ring), 64x256 with 3 / 2 stages, 128^2"""
+    128x160 (ragged LDS-DMA round, 1 .. 7 K tiles through the 3-stage ring), 64x256 with 3 / 2 stages, 128^2;
+    the SAM-H shapes (M >= 4096) also in f16, the storage type of that tower in the perf build"""
     g = torch.Generator().manual_seed(M + N + K)
     A, W = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.1
     bias = torch.randn(N, generator=g)
-    ref = rnd(A, 1) @ rnd(W, 1).t() + bias
-    out = torch.empty(M, N, device="cuda")
-    check(lib, lib.anyref_op_gemm(1, None, P(dev(A, 1)), P(dev(W, 1)), P(bias.cuda()), P(out), None, None, M, N, K, 0, 1))
-    close(out, ref, 1e-4 if K < 2048 else 4e-4)   # bf16 products are exact in f32; only the summation order differs
+    for ty in ((1, 2) if M >= 4096 else (1,)):
+        ref = rnd(A, ty) @ rnd(W, ty).t() + bias
+        out = torch.empty(M, N, device="cuda")
+        check(lib, lib.anyref_op_gemm(ty, None, P(dev(A, ty)), P(dev(W, ty)), P(bias.cuda()), P(out), None, None, M, N, K, 0, 1))
+        close(out, ref, 1e-4 if K < 2048 else 4e-4)   # 16-bit products are exact in f32; only the summation order differs
 
 
-@pytest.mark.parametrize("ty", [0, 1])
+@pytest.mark.parametrize("ty", [0, 1, 2])
 def test_gemm_row_map_and_typed_out(lib, ty):
     M, N, K = 200, 96, 64
     g = torch.Generator().manual_seed(5)
@@ -105,10 +109,10 @@ def test_gemm_row_map_and_typed_out(lib, ty):
     for m in range(M):
         if perm[m] >= 0:
             ref[perm[m]] = z[m]
-    out = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16 if ty == 1 else torch.float32)
+    out = torch.zeros(M, N, device="cuda", dtype=_DT[ty])
     check(lib, lib.anyref_op_gemm(ty, None, P(dev(A, ty)), P(dev(W, ty)), None, P(out), None, P(perm.cuda()), M, N,
                                   K, 0, 0))
-    close(out, ref, 1e-2 if ty else 1e-4)
+    close(out, ref, {0: 1e-4, 1: 1e-2, 2: 2e-3}[ty])
 
 
 @pytest.mark.parametrize("ty", [0, 1])
@@ -171,7 +175,7 @@ def ref_attention(q, k, v, scale, causal, kv_len, rel_h, rel_w, kw):
     return torch.einsum("bhqk,bkhd->bqhd", torch.softmax(s, -1), v)
 
 
-@pytest.mark.parametrize("ty", [0, 1])
+@pytest.mark.parametrize("ty", [0, 1, 2])
 @pytest.mark.parametrize("B,H,Sq,Sk,hd,causal", [
     (2, 3, 257, 257, 64, 0),      # CLIP
     (1, 4, 320, 320, 128, 1),     # LLaMA prefill
@@ -196,14 +200,14 @@ def test_attention(lib, ty, B, H, Sq, Sk, hd, causal):
         kv_len = torch.tensor([Sk - 7 * b for b in range(B)], dtype=torch.int32)
     scale = hd ** -0.5
     ref = ref_attention(rnd(q, ty), rnd(k, ty), rnd(v, ty), scale, causal, kv_len, None, None, 0)
-    o = torch.empty(B, Sq, H, hd, device="cuda", dtype=torch.bfloat16 if ty else torch.float32)
+    o = torch.empty(B, Sq, H, hd, device="cuda", dtype=_DT[ty])
     check(lib, lib.anyref_op_attention(ty, None, P(dev(q, ty)), P(dev(k, ty)), P(dev(v, ty)), P(o), B, H, Sq, Sk, hd,
                                        scale, causal, P(kv_len.cuda()) if kv_len is not None else None, None, None,
                                        0, 0))
-    close(o, ref, 3e-2 if ty else 3e-5)
+    close(o, ref, {0: 3e-5, 1: 3e-2, 2: 4e-3}[ty])
 
 
-@pytest.mark.parametrize("ty", [0, 1])
+@pytest.mark.parametrize("ty", [0, 1, 2])
 @pytest.mark.parametrize("B,H,size,hd", [(3, 2, 14, 80), (1, 2, 16, 64), (2, 3, 4, 64), (1, 2, 64, 80), (1, 1, 32, 80)])
 def test_sam_attention_rel_pos(lib, ty, B, H, size, hd):
     """windowed / global SAM attention incl. the decomposed rel-pos bias (image_encoder.py:231-392)."""
@@ -218,46 +222,51 @@ def test_sam_attention_rel_pos(lib, ty, B, H, size, hd):
     rel_w = torch.einsum("bnhwc,wkc->bnhwk", rq, tw[idx]).reshape(B, H, S, size)
     rh = torch.empty(B, H, S, size, device="cuda")
     rw = torch.empty(B, H, S, size, device="cuda")
-    check(lib, lib.anyref_op_rel_pos(ty, None, P(dev(q, ty)), P(th.cuda()), P(tw.cuda()), B, H, size, hd, P(rh), P(rw)))
-    close(rh, rel_h, 1e-4)
-    close(rw, rel_w, 1e-4)
+    if ty == 2:      # (the stand-alone rel-pos kernel is a bf16 / f32 test aid: take the bias from the reference)
+        rh, rw = rel_h.cuda().contiguous(), rel_w.cuda().contiguous()
+    else:
+        check(lib, lib.anyref_op_rel_pos(ty, None, P(dev(q, ty)), P(th.cuda()), P(tw.cuda()), B, H, size, hd, P(rh), P(rw)))
+        close(rh, rel_h, 1e-4)
+        close(rw, rel_w, 1e-4)
     scale = hd ** -0.5
     ref = ref_attention(qr, rnd(k, ty), rnd(v, ty), scale, False, None, rel_h, rel_w, size)
-    o = torch.empty(B, S, H, hd, device="cuda", dtype=torch.bfloat16 if ty else torch.float32)
+    o = torch.empty(B, S, H, hd, device="cuda", dtype=_DT[ty])
     check(lib, lib.anyref_op_attention(ty, None, P(dev(q, ty)), P(dev(k, ty)), P(dev(v, ty)), P(o), B, H, S, S, hd,
                                        scale, 0, None, P(rh), P(rw), size, size))
-    close(o, ref, 3e-2 if ty else 5e-5)
+    close(o, ref, {0: 5e-5, 1: 3e-2, 2: 4e-3}[ty])
 
 
+@pytest.mark.parametrize("ty", [1, 2])
 @pytest.mark.parametrize("B,H", [(1, 1), (5, 3)])
-def test_sam_window_attention_bias_from_tables(lib, B, H):
-    """SAM-H windows (14 x 14, hd 80, bf16): the kernel computes q . R^T itself from the rel-pos tables and applies
-    the get_rel_pos shift as a scatter (image_encoder.py:321-392); refused for shapes outside that form."""
+def test_sam_window_attention_bias_from_tables(lib, B, H, ty):
+    """SAM-H windows (14 x 14, hd 80, bf16 / f16): the kernel computes q . R^T itself from the rel-pos tables and applies
+    the get_rel_pos shift as a scatter (image_encoder.py:321-392), keys held in the row-padded order (one bias row per
+    16-key block); refused for shapes outside that form."""
     size, hd, ld = 14, 80, 128
     g = torch.Generator().manual_seed(B * 7 + H)
     S = size * size
     q, k, v = (torch.randn(B, S, H, hd, generator=g) for _ in range(3))
-    th, tw = (rnd(torch.randn(2 * size - 1, hd, generator=g) * 0.3, 1) for _ in range(2))
+    th, tw = (rnd(torch.randn(2 * size - 1, hd, generator=g) * 0.3, ty) for _ in range(2))
     idx = torch.arange(size)[:, None] - torch.arange(size)[None, :] + size - 1
-    qr = rnd(q, 1)
+    qr = rnd(q, ty)
     rq = qr.permute(0, 2, 1, 3).reshape(B, H, size, size, hd)
     rel_h = torch.einsum("bnhwc,hkc->bnhwk", rq, th[idx]).reshape(B, H, S, size)
     rel_w = torch.einsum("bnhwc,wkc->bnhwk", rq, tw[idx]).reshape(B, H, S, size)
     scale = hd ** -0.5
-    ref = ref_attention(qr, rnd(k, 1), rnd(v, 1), scale, False, None, rel_h, rel_w, size)
+    ref = ref_attention(qr, rnd(k, ty), rnd(v, ty), scale, False, None, rel_h, rel_w, size)
     tab = torch.zeros(2, 2 * size, ld)                      # padded rows / columns as the model packs them
     tab[0, : 2 * size - 1, :hd], tab[1, : 2 * size - 1, :hd] = th, tw
-    tab = tab.bfloat16().cuda()
-    o = torch.empty(B, S, H, hd, device="cuda", dtype=torch.bfloat16)
-    check(lib, lib.anyref_op_attention_tab(None, P(dev(q, 1)), P(dev(k, 1)), P(dev(v, 1)), P(o), B, H, S, hd, scale,
+    tab = tab.to(_DT[ty]).cuda()
+    o = torch.empty(B, S, H, hd, device="cuda", dtype=_DT[ty])
+    check(lib, lib.anyref_op_attention_tab(ty, None, P(dev(q, ty)), P(dev(k, ty)), P(dev(v, ty)), P(o), B, H, S, hd, scale,
                                            P(tab[0]), P(tab[1]), ld, size, size))
-    close(o, ref, 3e-2)
+    close(o, ref, 3e-2 if ty == 1 else 4e-3)
     # the same call against the precomputed-bias path of the same kernel: only the f32 summation order differs
     o2 = torch.empty_like(o)
-    check(lib, lib.anyref_op_attention(1, None, P(dev(q, 1)), P(dev(k, 1)), P(dev(v, 1)), P(o2), B, H, S, S, hd, scale, 0,
+    check(lib, lib.anyref_op_attention(ty, None, P(dev(q, ty)), P(dev(k, ty)), P(dev(v, ty)), P(o2), B, H, S, S, hd, scale, 0,
                                        None, P(rel_h.cuda().contiguous()), P(rel_w.cuda().contiguous()), size, size))
-    close(o, o2.float(), 1e-2)
-    assert lib.anyref_op_attention_tab(None, P(dev(q, 1)), P(dev(k, 1)), P(dev(v, 1)), P(o), B, H, 100, hd, scale,
+    close(o, o2.float(), 1e-2 if ty == 1 else 2e-3)
+    assert lib.anyref_op_attention_tab(ty, None, P(dev(q, ty)), P(dev(k, ty)), P(dev(v, ty)), P(o), B, H, 100, hd, scale,
                                        P(tab[0]), P(tab[1]), ld, 10, 10) != 0      # not a resident-form shape
 
 

@@ -26,19 +26,19 @@ def asm_of(src, strict):
 def main():
     bad = 0
     allowed_scratch = ()
-    for src in ("gemm.hip", "gemv.hip", "attention.hip", "ops.hip"):
-        s = asm_of(src, strict=src in ("gemm.hip", "gemv.hip"))
+    for src in ("gemm.hip", "gemm_f16.hip", "gemv.hip", "attention.hip", "ops.hip"):
+        s = asm_of(src, strict=src in ("gemm.hip", "gemm_f16.hip", "gemv.hip"))
         for name, seg in re.findall(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)", s):
             if int(seg) > 0 and not any(a in name for a in allowed_scratch):
                 print(f"FAIL {src}: {name} uses {seg} bytes of scratch")
                 bad += 1
-        if src == "gemm.hip":
+        if src in ("gemm.hip", "gemm_f16.hip"):
             for m in re.finditer(r"^(_ZN6anyref16gemm_glds_kernel\S*):\n(.*?)\.Lfunc_end", s, re.S | re.M):
                 lines = m.group(2).split("\n")
                 n = sum(1 for k, l in enumerate(lines)
                         if "s_waitcnt vmcnt(0)" in l and any("ds_read" in x for x in lines[k + 1:k + 4]))
                 if n:
-                    print(f"FAIL gemm.hip: {m.group(1)} waits vmcnt(0) before {n} ds_read group(s)")
+                    print(f"FAIL {src}: {m.group(1)} waits vmcnt(0) before {n} ds_read group(s)")
                     bad += 1
     print("isa check:", "FAILED" if bad else "ok")
     return 1 if bad else 0
