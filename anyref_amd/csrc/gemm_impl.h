@@ -705,6 +705,7 @@ struct GemmKnobs {
   int gm = getenv("ANYREF_GEMM_GM") ? atoi(getenv("ANYREF_GEMM_GM")) : -1;
   int tile = getenv("ANYREF_GEMM_TILE") ? atoi(getenv("ANYREF_GEMM_TILE")) : -1;
   int m320 = getenv("ANYREF_GEMM_M320") ? atoi(getenv("ANYREF_GEMM_M320")) : 0;  // -1: no 320-row tiles
+  int ns320 = getenv("ANYREF_GEMM_NS320") ? atoi(getenv("ANYREF_GEMM_NS320")) : 3;  // stages of the 320 x 96 tile (2: round 2)
   int force128 = getenv("ANYREF_GEMM_FORCE128") ? atoi(getenv("ANYREF_GEMM_FORCE128")) : 0;  // probe: 3 = 128^2 NS3, 2 = NS2
 };
 static const GemmKnobs& knobs() {
@@ -960,13 +961,15 @@ void launch_gemm(const GemmArgs& a_in, hipStream_t s) {
         if (!a.w_fp8 && knobs().m320 >= 0 && a.M > 192 && a.M <= 320 && a.N >= 16384 && a.batch == 1 && cdiv(a.N, 96) <= cus) {
           // prefill gate/up (320 x 22016 x 4096): every workgroup owns a weight panel outright (all of M in one
           // tile, 230 panels on 256 CUs) instead of five 64-row workgroups sharing one: 7 % faster from cold weights
-          go(I320(), std::integral_constant<int, 96>(), I4(), I2(), I2(), "gemm_bf16_320x96");
+          if (knobs().ns320 == 2) go(I320(), std::integral_constant<int, 96>(), I4(), I2(), I2(), "gemm_bf16_320x96");
+          else go(I320(), std::integral_constant<int, 96>(), I4(), I2(), I3(), "gemm_bf16_320x96s3");
           return;
         }
         if (!a.w_fp8 && knobs().m320 >= 0 && a.M > 192 && a.M <= 320 && a.batch == 2 && a.N >= 8192 &&
             (int64_t)cdiv(a.N, 96) * 2 <= cus) {
           // prefill qkv as two K slices (128 panels x 2 = 256 workgroups, a panel per workgroup); the RoPE kernel adds them
-          go(I320(), std::integral_constant<int, 96>(), I4(), I2(), I2(), "gemm_bf16_320x96");
+          if (knobs().ns320 == 2) go(I320(), std::integral_constant<int, 96>(), I4(), I2(), I2(), "gemm_bf16_320x96");
+          else go(I320(), std::integral_constant<int, 96>(), I4(), I2(), I3(), "gemm_bf16_320x96s3");
           return;
         }
         if (!a.w_fp8 && knobs().m320 >= 0 && a.M > 192 && a.M <= 320 && a.batch > 1 && (int64_t)cdiv(a.N, 64) * a.batch <= cus &&

@@ -15,28 +15,34 @@ import glob
 import json
 import sys
 
-TAGS = {  # bench.py roofline tag -> kernel-name prefix
-    "gemv_bf16_x8": "gemv_kernel<anyref::bf16, 1, false, 8, false>",
-    "gemv_bf16_x24": "gemv_kernel<anyref::bf16, 1, false, 24, false>",
-    "gemv_bf16_swiglu_x8": "gemv_kernel<anyref::bf16, 1, true, 8, false>",
-    "gemm_bf16_256x256": "gemm_glds_kernel<256, 256, 2, 4, 2, false>",
-    "gemm_bf16_256x320": "gemm_glds_kernel<256, 320, 2, 4, 2, false>",
-    "gemm_bf16_128x128g": "gemm_glds_kernel<128, 128, 2, 4, 2, false>",
-    "gemm_bf16_128x128s3": "gemm_glds_kernel<128, 128, 2, 4, 3, false>",
-    "gemm_bf16_64x256": "gemm_glds_kernel<64, 256, 1, 4, 2, false>",
-    "gemm_bf16_64x256s3": "gemm_glds_kernel<64, 256, 1, 4, 3, false>",
-    "gemm_bf16_128x160s3": "gemm_glds_kernel<128, 160, 4, 2, 3, false>",
-    "gemm_bf16_320x96": "gemm_glds_kernel<320, 96, 4, 2, 2, false>",
-    "gemm_bf16_320x64": "gemm_glds_kernel<320, 64, 4, 2, 3, false>",
-    "gemm_bf16_128x128": "gemm_kernel<anyref::bf16, 128, 128, 64>",
-    "gemm_bf16_64x128": "gemm_kernel<anyref::bf16, 64, 128, 64>",
-    "gemm_bf16_64x64": "gemm_kernel<anyref::bf16, 64, 64, 64>",
-    "attn_bf16_hd80": "attn_kernel<anyref::bf16, 80, 4, 0, 0>",
-    "attn_bf16_hd80_w8": "attn_kernel<anyref::bf16, 80, 8, 64, 0>",
-    "attn_bf16_hd80_w13_res": "attn_kernel<anyref::bf16, 80, 13, 48, 5>",
-    "attn_bf16_hd128": "attn_kernel<anyref::bf16, 128, 4, 0, 0>",
-    "attn_bf16_hd64_res": "attn_kernel<anyref::bf16, 64, 4, 64, 5>",
-    "decode_attn_bf16": "decode_attn_kernel<anyref::bf16, 128>",
+import re
+
+def _glds(bm, bn, wm, wn, ns, ty):
+    # gemm_glds_kernel<BM, BN, WM, WN, NS, W8 = false, PERSIST, T>: the walking (capped) variant counts with its tile
+    return [rf"gemm_glds_kernel<{bm}, {bn}, {wm}, {wn}, {ns}, false, (false|true), anyref::{ty}>"]
+
+
+TAGS = {  # bench.py roofline tag -> regexes of the kernel names (rocprofv3 Kernel_Name without "void anyref::")
+    "gemv_bf16_x8": [r"gemv_kernel<anyref::bf16, 1, false, 8, false, (false|true)>"],      # plain and wave-pair split
+    "gemv_bf16_x24": [r"gemv_kernel<anyref::bf16, 1, false, 24, false, (false|true)>"],
+    "gemv_bf16_swiglu_x8": [r"gemv_kernel<anyref::bf16, 1, true, 8, false, (false|true)>"],
+    "gemm_bf16_256x256": _glds(256, 256, 2, 4, 2, "bf16"), "gemm_f16_256x256": _glds(256, 256, 2, 4, 2, "f16"),
+    "gemm_bf16_256x320": _glds(256, 320, 2, 4, 2, "bf16"), "gemm_f16_256x320": _glds(256, 320, 2, 4, 2, "f16"),
+    "gemm_bf16_128x128g": _glds(128, 128, 2, 4, 2, "bf16"), "gemm_f16_128x128g": _glds(128, 128, 2, 4, 2, "f16"),
+    "gemm_bf16_128x128s3": _glds(128, 128, 2, 4, 3, "bf16"), "gemm_f16_128x128s3": _glds(128, 128, 2, 4, 3, "f16"),
+    "gemm_bf16_128x160s3": _glds(128, 160, 4, 2, 3, "bf16"), "gemm_f16_128x160s3": _glds(128, 160, 4, 2, 3, "f16"),
+    "gemm_bf16_64x256": _glds(64, 256, 1, 4, 2, "bf16"), "gemm_bf16_64x256s3": _glds(64, 256, 1, 4, 3, "bf16"),
+    "gemm_bf16_320x96": _glds(320, 96, 4, 2, 2, "bf16"), "gemm_bf16_320x64": _glds(320, 64, 4, 2, 3, "bf16"),
+    "gemm_bf16_128x128": [r"gemm_kernel<anyref::bf16, 128, 128, 64>"],
+    "gemm_bf16_64x128": [r"gemm_kernel<anyref::bf16, 64, 128, 64>"],
+    "gemm_bf16_64x64": [r"gemm_kernel<anyref::bf16, 64, 64, 64>"],
+    "attn_f16_hd80_w8": [r"attn_(walk_)?kernel<anyref::f16, 80, 8, 64, 0>"],
+    "attn_f16_hd80_w13_res": [r"attn_kernel<anyref::f16, 80, 13, 48, 5>"],
+    "attn_bf16_hd80_w8": [r"attn_(walk_)?kernel<anyref::bf16, 80, 8, 64, 0>"],
+    "attn_bf16_hd80_w13_res": [r"attn_kernel<anyref::bf16, 80, 13, 48, 5>"],
+    "attn_bf16_hd128": [r"attn_kernel<anyref::bf16, 128, 4, 0, 0>"],
+    "attn_bf16_hd64_res": [r"attn_kernel<anyref::bf16, 64, 4, 64, 5>"],
+    "decode_attn_bf16": [r"decode_attn_kernel<anyref::bf16, 128>"],
 }
 
 
@@ -52,13 +58,23 @@ def agg(d, cname):
     return out
 
 
+def match(table, pats):
+    """sum / launches over every kernel name one of the regexes matches in full"""
+    tot, n, names = 0.0, 0, []
+    for k, (v, c) in table.items():
+        if any(re.fullmatch(p, k) for p in pats):
+            tot, n = tot + v, n + c
+            names.append(k)
+    return tot, n, names
+
+
 fe, wr = agg(sys.argv[1], "FETCH_SIZE"), agg(sys.argv[2], "WRITE_SIZE")
 res = {}
-for tag, name in TAGS.items():
-    if name in fe:
-        f, n = fe[name]
-        w, nw = wr.get(name, [0.0, 1])
-        res[tag] = {"kernel": name, "launches": n, "fetch_bytes_per_launch": 2 * f / n * 1024,
+for tag, pats in TAGS.items():
+    f, n, names = match(fe, pats)
+    if n:
+        w, nw, _ = match(wr, pats)
+        res[tag] = {"kernel": " | ".join(sorted(names)), "launches": n, "fetch_bytes_per_launch": 2 * f / n * 1024,
                     "write_bytes_per_launch": w / max(nw, 1) * 1024,
                     "hbm_bytes_per_launch": 2 * f / n * 1024 + w / max(nw, 1) * 1024,
                     "note": "FETCH_SIZE doubled (gfx950 counts wide coalesced reads at half), KiB -> bytes"}
