@@ -40,6 +40,13 @@ __device__ __forceinline__ void st_x(float* p, float v) {
 // (The previous form -- scores to LDS, block softmax, second sweep for V -- had 7 dependent round
 // trips and 6 barriers: 10.1 us per layer at n = 330; this one 4 round trips.)
 // ---------------------------------------------------------------------------------------------
+// exp of the softmax: the fast hardware form (v_exp_f32) for the 16-bit build, libm's for the f32 parity build
+template <typename T>
+__device__ __forceinline__ float dexp(float x) {
+  if constexpr (sizeof(T) == 2) return __expf(x);
+  else return expf(x);
+}
+
 template <typename T, int HD, bool COH>
 __device__ __forceinline__ void decode_attn_body(const float* __restrict__ qkv, const int* __restrict__ pos,
                                                  const float* __restrict__ cs_tab, T* __restrict__ kc,
@@ -71,17 +78,25 @@ __device__ __forceinline__ void decode_attn_body(const float* __restrict__ qkv, 
       vv[u] = j < p ? *reinterpret_cast<const uint4v*>(vc + o) : uint4v{0, 0, 0, 0};
     }
   };
+  // Order in the (in-order) vector-memory queue: this step's q / k / v row (independent of the position) and the RoPE
+  // table row FIRST, the first K/V batch behind them -- the rotation then waits for a few hundred bytes, not for the
+  // batch's 64 KB (round 2 issued the batch first and the rotation sat behind it).
+  float q1 = 0.f, q2 = 0.f, k1 = 0.f, k2 = 0.f, v1 = 0.f, v2 = 0.f, cs = 0.f, sn = 0.f;
+  if (tid < HALF) {
+    const int d = tid;
+    q1 = ld_x<COH>(&row[h * HD + d]); q2 = ld_x<COH>(&row[h * HD + d + HALF]);
+    k1 = ld_x<COH>(&row[(H + h) * HD + d]); k2 = ld_x<COH>(&row[(H + h) * HD + d + HALF]);
+    v1 = ld_x<COH>(&row[(2 * H + h) * HD + d]); v2 = ld_x<COH>(&row[(2 * H + h) * HD + d + HALF]);
+    cs = cs_tab[((int64_t)p * 2) * HALF + d]; sn = cs_tab[((int64_t)p * 2 + 1) * HALF + d];
+  }
   load_batch(0, kcur, vcur);  // in flight while the new token is rotated and appended
 
   if (tid < HALF) {
     const int d = tid;
-    const float cs = cs_tab[((int64_t)p * 2) * HALF + d], sn = cs_tab[((int64_t)p * 2 + 1) * HALF + d];
-    const float q1 = ld_x<COH>(&row[h * HD + d]), q2 = ld_x<COH>(&row[h * HD + d + HALF]);
-    const float k1 = ld_x<COH>(&row[(H + h) * HD + d]), k2 = ld_x<COH>(&row[(H + h) * HD + d + HALF]);
     const T qa = from_f32<T>(q1 * cs - q2 * sn), qb = from_f32<T>(q2 * cs + q1 * sn);
     const T ka = from_f32<T>(k1 * cs - k2 * sn), kb = from_f32<T>(k2 * cs + k1 * sn);
-    const T va = from_f32<T>(ld_x<COH>(&row[(2 * H + h) * HD + d]));
-    const T vb = from_f32<T>(ld_x<COH>(&row[(2 * H + h) * HD + d + HALF]));
+    const T va = from_f32<T>(v1);
+    const T vb = from_f32<T>(v2);
     const int64_t co = cbase + (int64_t)p * H * HD;
     kc[co + d] = ka; kc[co + d + HALF] = kb;
     vc[co + d] = va; vc[co + d + HALF] = vb;
@@ -125,13 +140,13 @@ __device__ __forceinline__ void decode_attn_body(const float* __restrict__ qkv, 
       mx = fmaxf(mx, sc[u]);
     }
     if (mx > -INFINITY) {  // this lane group has seen a key (uniform within the group)
-      const float alpha = expf(m_run - mx);  // m_run = -inf -> 0
+      const float alpha = dexp<T>(m_run - mx);  // m_run = -inf -> 0
       l_run *= alpha;
 #pragma unroll
       for (int i = 0; i < VEC; ++i) acc[i] *= alpha;
 #pragma unroll
       for (int u = 0; u < UN; ++u) {
-        const float pj = expf(sc[u] - mx);  // masked key: exp(-inf) = 0
+        const float pj = dexp<T>(sc[u] - mx);  // masked key: exp(-inf) = 0
         l_run += pj;
 #pragma unroll
         for (int i = 0; i < VEC; ++i) acc[i] = fmaf(pj, vf[u][i], acc[i]);
@@ -153,14 +168,22 @@ __device__ __forceinline__ void decode_attn_body(const float* __restrict__ qkv, 
     ls[slice] = l_run;
   }
   __syncthreads();
-  if (tid < HD) {  // merge the KPI partial states (slice 0 always holds key 0, so M is finite)
+  // merge the KPI partial states (slice 0 always holds key 0, so M is finite).  The weights exp(m_s - M) are the same
+  // for every output column: one lane group computes them side by side (the HD merge threads used to evaluate all KPI
+  // of them each, one after the other: ~1.5 us of a 10 us kernel)
+  float* wts = ls + KPI;  // [KPI]
+  if (tid < KPI) {
     float M = -INFINITY;
 #pragma unroll 8
     for (int sI = 0; sI < KPI; ++sI) M = fmaxf(M, ms[sI]);
+    wts[tid] = dexp<T>(ms[tid] - M);  // empty group: exp(-inf) = 0
+  }
+  __syncthreads();
+  if (tid < HD) {
     float o = 0.f, l = 0.f;
 #pragma unroll 8
     for (int sI = 0; sI < KPI; ++sI) {
-      const float w = expf(ms[sI] - M);  // empty group: exp(-inf) = 0
+      const float w = wts[sI];
       o = fmaf(w, part[sI * HD + tid], o);
       l = fmaf(w, ls[sI], l);
     }
