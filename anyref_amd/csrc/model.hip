@@ -1802,7 +1802,8 @@ void Model<T, TS>::generate(hipStream_t s, const float* clip_images, const float
   // idle), none during prefill (MFMA-bound itself), the rest per decode step; larger batches bring more encoder work
   // than the loop can hide at a reduced share: queued whole, uncapped, after prefill.
   const int nblk = (int)sam_blocks_.size();
-  const bool fed = B == 1 && side_wgs_ > 0 && overlap_ && sizeof(T) == 2;
+  static const bool any_b = getenv("ANYREF_SIDE_ANYB") != nullptr;  // lab: the CU share for batches > 1 too
+  const bool fed = (B == 1 || any_b) && side_wgs_ > 0 && overlap_ && sizeof(T) == 2;
   const int per_step = std::max(1, (nblk + side_steps_ - 1) / std::max(1, side_steps_));
   if (fed) {
     fork_sam(s, sam_images, B, true);
