@@ -441,3 +441,42 @@ def test_raw_mel_audio_through_imagebind_on_the_gpu():
     out2, masks2, _ = m.generate(clip, ids[0][None], sam, sizes, H, W, audios=[emb_cpu[0]], max_new_tokens=5)
     assert out2[0].cpu().tolist() == want.tolist()
     assert (masks2[0].cpu() - ref["pred_masks"][0]).abs().max().item() <= MASK_TOL
+
+
+def test_side_stream_cu_share_is_bit_identical():
+    """`anyref_set_side_share`: the SAM encoder's GEMM / attention launches capped at n workgroups (walking kernels for
+    the 128-row tiles and the global attention, row-block / window-group launches for the 256-row tiles and the 13-wave
+    window attention) and its blocks queued a few per decode step -- same ids, hidden states and masks bit for bit as the
+    uncapped encoder queued whole, at SAM-H's real width (1280, 16 heads of 80, 1024^2: every capped form is taken), with
+    and without an EOS that ends the loop before the encoder is queued in full."""
+    import dataclasses
+    from anyref_amd.config import SamConfig
+    from anyref_amd.model import AnyRefForCausalLM
+    cfg = config_tiny()
+    cfg = dataclasses.replace(cfg, sam=SamConfig(img_size=1024, patch=16, dim=1280, depth=3, heads=16, window=14, global_idx=(2,)))
+    sd = synth_state_dict(cfg, seed=61, init="fan_in")
+    g = torch.Generator().manual_seed(62)
+    clip = torch.randn(1, 3, 224, 224, generator=g)
+    sam = torch.randn(1, 3, 1024, 1024, generator=g)
+    ids = torch.cat([torch.tensor([1, IMAGE_TOKEN_INDEX]), torch.randint(3, 990, (14,), generator=g)])[None]
+    sizes, H, W = [(1024, 1024)], [1024], [1024]
+    m = AnyRefForCausalLM.from_state_dict(cfg, {k: v.cuda() for k, v in sd.items()}, mode="perf", max_batch=1, max_seg=4)
+    m.config.eos_token_id = None
+    m.set_side_share(0)
+    o0, _, _ = m.generate(clip, ids, sam, sizes, H, W, max_new_tokens=8)
+    gen = o0[0, ids.shape[1]:].tolist()
+    m.set_seg_token_idx(int(gen[2]))
+    for eos in (None, int(gen[4]) if gen[4] != gen[2] else None):
+        m.config.eos_token_id = eos
+        ref = None
+        for cap, steps in ((0, 6), (128, 6), (40, 1), (128, 2), (256, 3)):
+            m.set_side_share(cap, steps)
+            (o, masks, _), ex = m.generate(clip, ids, sam, sizes, H, W, max_new_tokens=8, _return_extras=True)
+            got = (o.cpu(), ex["hidden"].cpu(), masks[0].cpu(), ex["low_res"].cpu())
+            if ref is None:
+                ref = got
+                assert got[2].shape[0] >= 1
+            else:
+                for a, b in zip(ref, got):
+                    assert torch.equal(a, b), (eos, cap, steps)
+    m.set_side_share(128, 6)
