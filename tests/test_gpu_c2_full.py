@@ -31,7 +31,8 @@ T_NEW = 10
 N_PROMPTS = 8          # ids-match rate is taken over these; the first N_MASKS also compare mask logits
 N_MASKS = 2
 # perf-mode bounds = 2 x the error measured on MI355X (gpurun_out/r2_t3.log), relative to the range
-PERF_REL_BOUND = {"normal": 0.026, "fan_in": 0.005}      # measured 1.3e-2 (teacher-forced) / 2.4e-3
+# (round 3, SAM encoder in f16: fan_in measured 5.3e-4 .. 6.8e-4; the all-bf16 build of round 2 measured 2.4e-3)
+PERF_REL_BOUND = {"normal": 0.026, "fan_in": 0.0014}     # measured 1.3e-2 (teacher-forced) / 6.8e-4
 
 
 def _inputs(cfg, n, seed):

@@ -84,3 +84,50 @@ def test_forward_tail_vs_reference(name, mode):
            "loss": float(x["lm_loss"]) + float(ce + dice), "lm_loss": float(x["lm_loss"])}
     for k in keys:
         assert abs(got[k] - float(GLUE[f"{name}.{k}"])) < (1e-4 if mode == "parity" else 1e-3), (k, got[k], float(GLUE[f"{name}.{k}"]))
+
+
+def test_back_to_back_seg_tail_calls_do_not_share_staged_indices():
+    """The [SEG] (image, row) indices of a call go to the device through a pinned staging region, and `seg_tail` returns
+    without a host sync: the copy sits in the stream behind the previous call's SAM encoder.  Three calls with DIFFERENT
+    [SEG] positions queued back to back must each gather their own rows (the region is guarded by an event: the host
+    waits for the last copy queued from it before rewriting it) -- results equal to the same calls run with a device
+    sync in between."""
+    names = [n for n in gg.GEN_CASES if not int(GLUE[n + ".masks_none"]) and gg.case_inputs(n)["c"]["bs"] == 1
+             and not gg.case_inputs(n)["c"].get("seg_list", False) and gg.case_inputs(n)["c"]["rephrase"] == 0][:1]
+    assert names, "no single-image [SEG] case among the glue fixtures"
+    x = gg.case_inputs(names[0])
+    c = x["c"]
+    m = _model(c, "parity")
+    seq, n = x["seq"], x["seq"].shape[1]
+    seg_pos = [int(p) for p in torch.where(seq[0] == gg.SEG)[0]]
+    assert seg_pos
+    # variants of the sequence with the [SEG] moved to other answer positions (different hidden rows are gathered)
+    variants = [seq]
+    for shift in (1, 2):
+        v = seq.clone()
+        p = seg_pos[0]
+        q = min(n - 1, p + shift)
+        if q != p:
+            a, b = int(v[0, p]), int(v[0, q])
+            v[0, p], v[0, q] = b, a
+        variants.append(v)
+    args = ([n], [c["L"]], x["hidden"], x["attn"].mean(1), c["sizes"], [h for h, _ in c["hw"]], [w for _, w in c["hw"]])
+
+    def run(sync):
+        outs = []
+        for v in variants:
+            masks, nseg = m.seg_tail(x["sam"], v, *args, teacher=False)
+            if sync:
+                torch.cuda.synchronize()
+            outs.append(masks)
+        torch.cuda.synchronize()
+        return [None if o is None else o[0].clone() for o in outs]
+
+    want, got = run(True), run(False)
+    assert any(w is not None for w in want)
+    for a, b in zip(want, got):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert torch.equal(a, b)
+    same = [torch.equal(want[0], w) for w in want[1:] if w is not None and w.shape == want[0].shape]
+    assert not all(same), "the variants should gather different rows"

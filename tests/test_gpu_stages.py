@@ -20,6 +20,8 @@ from oracle import anyref_oracle as O  # noqa: E402
 # measured on MI355X, relative to the stage output's scale (5.4e-3: a 2-layer LLaMA's hidden states; SAM-H-width
 # encoder 3.8e-3; CLIP tower 3e-3 -- gpurun_out/r2_t3.log); quantified end to end in test_gpu_e2e.py / test_gpu_c2_full.py
 TOL = {"parity": 2e-4, "perf": 1.1e-2}
+# the SAM image encoder runs in f16 in the perf build (round 3): measured 3.1e-4 .. 5.4e-4 of the output's scale (bf16: 3.8e-3)
+TOL_SAM = {"parity": 2e-4, "perf": 1.1e-3}
 
 
 def close(got, ref, tol, what=""):
@@ -46,7 +48,7 @@ def test_sam_half(name, mode):
     sd = synth_state_dict(cfg, seed=seed, scale=0.05)
     img, text = mg.golden_inputs(cfg, seed)
     m = build(cfg, sd, mode, max_batch=2, max_seg=3)
-    tol = TOL[mode]
+    tol = TOL_SAM[mode]
     with torch.no_grad():
         emb_ref = O.sam_image_encoder(sd, cfg, img)
     emb = m.sam_encode(img)
@@ -116,8 +118,8 @@ def test_sam_h_shaped_encoder_vs_oracle(mode):
     m = build(cfg, sd, mode, max_batch=1, max_seg=2)
     emb = m.sam_encode(img)
     assert emb.shape == emb_ref.shape == (1, 256, 64, 64)
-    e1 = close(emb, emb_ref, TOL[mode], "SAM-H-shaped image encoder vs oracle")
-    e2 = close(emb[:, ::4, ::2, ::2], fx["emb"], TOL[mode], "SAM-H-shaped image encoder vs reference golden")
+    e1 = close(emb, emb_ref, TOL_SAM[mode], "SAM-H-shaped image encoder vs oracle")
+    e2 = close(emb[:, ::4, ::2, ::2], fx["emb"], TOL_SAM[mode], "SAM-H-shaped image encoder vs reference golden")
     print(f"[{mode}] SAM-H-width encoder max-abs-err vs oracle {e1:.3e}, vs reference {e2:.3e} (range {float(fx['absmax']):.2f})")
 
 
@@ -166,5 +168,5 @@ def test_rel_pos_interpolation_vs_reference(mode):
         emb_ref = O.sam_image_encoder(sd, cfg, img)
     m = build(cfg, sd, mode, max_batch=2, max_seg=2)
     emb = m.sam_encode(img)
-    close(emb, emb_ref, TOL[mode], "encoder with resampled rel_pos tables vs oracle")
-    close(emb[:, ::2], fx["emb"], TOL[mode], "encoder with resampled rel_pos tables vs reference golden")
+    close(emb, emb_ref, TOL_SAM[mode], "encoder with resampled rel_pos tables vs oracle")
+    close(emb[:, ::2], fx["emb"], TOL_SAM[mode], "encoder with resampled rel_pos tables vs reference golden")
