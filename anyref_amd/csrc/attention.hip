@@ -17,6 +17,10 @@
 
 #include "kernels.h"
 
+#ifndef ANYREF_ATTN_PAIRED_V
+#define ANYREF_ATTN_PAIRED_V 1
+#endif
+
 namespace anyref {
 
 template <typename T>
@@ -128,6 +132,49 @@ __device__ inline void lds_tr_blocks<8>(uint32_t addr, uint2v (&f)[8]) {
       "ds_read_b64_tr_b16 %6, %8 offset:192\n\tds_read_b64_tr_b16 %7, %8 offset:224\n\ts_waitcnt lgkmcnt(0)"
       : "=&v"(f[0]), "=&v"(f[1]), "=&v"(f[2]), "=&v"(f[3]), "=&v"(f[4]), "=&v"(f[5]), "=&v"(f[6]), "=&v"(f[7])
       : "v"(addr) : "memory");
+}
+
+// Two key blocks' worth of transposed V reads (2 x DB) behind ONE wait: halves the exposed LDS round trips of the P V
+// phase (each wave used to serialise NB x (DB reads -> wait -> DB MFMAs) per tile)
+template <int DB>
+__device__ inline void lds_tr_blocks2(uint32_t a0, uint32_t a1, uint2v (&f0)[DB], uint2v (&f1)[DB]);
+template <>
+__device__ inline void lds_tr_blocks2<4>(uint32_t a0, uint32_t a1, uint2v (&f0)[4], uint2v (&f1)[4]) {
+  asm volatile(
+      "ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %8 offset:32\n\t"
+      "ds_read_b64_tr_b16 %2, %8 offset:64\n\tds_read_b64_tr_b16 %3, %8 offset:96\n\t"
+      "ds_read_b64_tr_b16 %4, %9\n\tds_read_b64_tr_b16 %5, %9 offset:32\n\t"
+      "ds_read_b64_tr_b16 %6, %9 offset:64\n\tds_read_b64_tr_b16 %7, %9 offset:96\n\ts_waitcnt lgkmcnt(0)"
+      : "=&v"(f0[0]), "=&v"(f0[1]), "=&v"(f0[2]), "=&v"(f0[3]), "=&v"(f1[0]), "=&v"(f1[1]), "=&v"(f1[2]), "=&v"(f1[3])
+      : "v"(a0), "v"(a1) : "memory");
+}
+template <>
+__device__ inline void lds_tr_blocks2<5>(uint32_t a0, uint32_t a1, uint2v (&f0)[5], uint2v (&f1)[5]) {
+  asm volatile(
+      "ds_read_b64_tr_b16 %0, %10\n\tds_read_b64_tr_b16 %1, %10 offset:32\n\t"
+      "ds_read_b64_tr_b16 %2, %10 offset:64\n\tds_read_b64_tr_b16 %3, %10 offset:96\n\t"
+      "ds_read_b64_tr_b16 %4, %10 offset:128\n\t"
+      "ds_read_b64_tr_b16 %5, %11\n\tds_read_b64_tr_b16 %6, %11 offset:32\n\t"
+      "ds_read_b64_tr_b16 %7, %11 offset:64\n\tds_read_b64_tr_b16 %8, %11 offset:96\n\t"
+      "ds_read_b64_tr_b16 %9, %11 offset:128\n\ts_waitcnt lgkmcnt(0)"
+      : "=&v"(f0[0]), "=&v"(f0[1]), "=&v"(f0[2]), "=&v"(f0[3]), "=&v"(f0[4]), "=&v"(f1[0]), "=&v"(f1[1]), "=&v"(f1[2]),
+        "=&v"(f1[3]), "=&v"(f1[4])
+      : "v"(a0), "v"(a1) : "memory");
+}
+template <>
+__device__ inline void lds_tr_blocks2<8>(uint32_t a0, uint32_t a1, uint2v (&f0)[8], uint2v (&f1)[8]) {
+  asm volatile(
+      "ds_read_b64_tr_b16 %0, %16\n\tds_read_b64_tr_b16 %1, %16 offset:32\n\t"
+      "ds_read_b64_tr_b16 %2, %16 offset:64\n\tds_read_b64_tr_b16 %3, %16 offset:96\n\t"
+      "ds_read_b64_tr_b16 %4, %16 offset:128\n\tds_read_b64_tr_b16 %5, %16 offset:160\n\t"
+      "ds_read_b64_tr_b16 %6, %16 offset:192\n\tds_read_b64_tr_b16 %7, %16 offset:224\n\t"
+      "ds_read_b64_tr_b16 %8, %17\n\tds_read_b64_tr_b16 %9, %17 offset:32\n\t"
+      "ds_read_b64_tr_b16 %10, %17 offset:64\n\tds_read_b64_tr_b16 %11, %17 offset:96\n\t"
+      "ds_read_b64_tr_b16 %12, %17 offset:128\n\tds_read_b64_tr_b16 %13, %17 offset:160\n\t"
+      "ds_read_b64_tr_b16 %14, %17 offset:192\n\tds_read_b64_tr_b16 %15, %17 offset:224\n\ts_waitcnt lgkmcnt(0)"
+      : "=&v"(f0[0]), "=&v"(f0[1]), "=&v"(f0[2]), "=&v"(f0[3]), "=&v"(f0[4]), "=&v"(f0[5]), "=&v"(f0[6]), "=&v"(f0[7]),
+        "=&v"(f1[0]), "=&v"(f1[1]), "=&v"(f1[2]), "=&v"(f1[3]), "=&v"(f1[4]), "=&v"(f1[5]), "=&v"(f1[6]), "=&v"(f1[7])
+      : "v"(a0), "v"(a1) : "memory");
 }
 
 __device__ inline uint32_t pack_bf16x2(float lo, float hi) { return (uint32_t)f2bf(lo).x | ((uint32_t)f2bf(hi).x << 16); }
@@ -523,6 +570,24 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const int bx, const
         // this lane's address inside its group's 4x16 block: row q = (lane&15)>>2, columns 4p
         const uint32_t vbase = (uint32_t)(reinterpret_cast<const char*>(Vs) - smem) +  // dynamic LDS starts at 0
                                (uint32_t)((slot * BKV + 4 * g + (qi >> 2)) * LDV + 4 * (qi & 3)) * 2u;
+        // key blocks in pairs where the registers allow (not the 13-wave window form at its 128-VGPR limit)
+        constexpr bool PAIRED = (DB == 4 || DB == 5 || DB == 8) && NB % 2 == 0 && NWV <= 8 && ANYREF_ATTN_PAIRED_V;
+        if constexpr (PAIRED) {
+#pragma unroll
+          for (int nb = 0; nb < NB; nb += 2) {
+            uint2v vt0[DB], vt1[DB];
+            lds_tr_blocks2<DB>(vbase + (uint32_t)(nb * 16 * LDV * 2), vbase + (uint32_t)((nb + 1) * 16 * LDV * 2), vt0, vt1);
+            __builtin_amdgcn_sched_barrier(0);
+            const uint2v pb0 = uint2v{pack2_from_f32<T>(sv[nb][0], sv[nb][1]), pack2_from_f32<T>(sv[nb][2], sv[nb][3])};
+            const uint2v pb1 = uint2v{pack2_from_f32<T>(sv[nb + 1][0], sv[nb + 1][1]), pack2_from_f32<T>(sv[nb + 1][2], sv[nb + 1][3])};
+#pragma unroll
+            for (int d = 0; d < DB; ++d)
+              ot[d] = mfma_16x16x16<T>(__builtin_bit_cast(short4v, vt0[d]), __builtin_bit_cast(short4v, pb0), ot[d]);
+#pragma unroll
+            for (int d = 0; d < DB; ++d)
+              ot[d] = mfma_16x16x16<T>(__builtin_bit_cast(short4v, vt1[d]), __builtin_bit_cast(short4v, pb1), ot[d]);
+          }
+        } else {
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
           uint2v vt[DB];
@@ -532,6 +597,7 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const int bx, const
 #pragma unroll
           for (int d = 0; d < DB; ++d)
             ot[d] = mfma_16x16x16<T>(__builtin_bit_cast(short4v, vt[d]), __builtin_bit_cast(short4v, pb), ot[d]);
+        }
         }
       } else {
 #pragma unroll
