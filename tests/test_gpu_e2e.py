@@ -480,3 +480,39 @@ def test_side_stream_cu_share_is_bit_identical():
                 for a, b in zip(ref, got):
                     assert torch.equal(a, b), (eos, cap, steps)
     m.set_side_share(128, 6)
+
+
+def test_handle_destroyed_on_another_thread_releases_its_workspaces():
+    """The split-K / attention workspaces are pooled per stream in a process-wide table (not per thread): a handle built
+    and used on one thread and destroyed on another (Python's GC does that) must still find and free the workspaces of
+    the streams it owns -- device memory returns to where it was, and a new handle works afterwards."""
+    import gc
+    import threading
+    from anyref_amd.model import AnyRefForCausalLM
+    cfg = config_tiny()
+    sd = {k: v.cuda() for k, v in synth_state_dict(cfg, seed=71, scale=0.05).items()}
+    clip, sam, ids = make_inputs(cfg, 1, seed=72, L=16)
+    ids_p, _ = pad(ids)
+    sizes, H, W = [(224, 224)], [224], [224]
+    box = {}
+
+    def build_and_run():
+        m = AnyRefForCausalLM.from_state_dict(cfg, sd, mode="perf", max_batch=1, max_seg=4)
+        m.config.eos_token_id = None
+        box["out"] = m.generate(clip, ids_p, sam, sizes, H, W, max_new_tokens=4)[0].cpu()
+        box["m"] = m
+
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    t = threading.Thread(target=build_and_run)
+    t.start()
+    t.join()
+    assert "out" in box
+    del box["m"]                       # destroyed here, on the main thread
+    gc.collect()
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 64 << 20, f"{(free0 - free1) >> 20} MiB still held after the handle was destroyed"
+    m2 = AnyRefForCausalLM.from_state_dict(cfg, sd, mode="perf", max_batch=1, max_seg=4)
+    m2.config.eos_token_id = None
+    assert torch.equal(m2.generate(clip, ids_p, sam, sizes, H, W, max_new_tokens=4)[0].cpu(), box["out"])
