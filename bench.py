@@ -339,6 +339,26 @@ def main():
             # algorithmic FLOPs of one image (S = 320, T = 10, bf16) x images/s over the dense bf16 MFMA peak
             res["mfma_frac_e2e"] = round(FLOP_PER_IMAGE_C2 * ips / world / (PEAK_BF16_TFLOPS * 1e12), 4)
             res["flop_per_image"] = FLOP_PER_IMAGE_C2
+        if full and config == "c2" and world == 1 and B == 1 and mode == "perf":
+            # untimed: the MFMA-bound stages alone (no co-running stream), against the dense bf16 / f16 MFMA peak;
+            # algorithmic FLOPs from SURVEY.md §8d (S = 320 prompt)
+            def stage_ms(f, n=5):
+                for _ in range(2):
+                    f()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    f()
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t0) / n * 1e3
+            emb = torch.randn(1, 320, cfg.llm.dim, device=dev) * 0.02
+            st = {"sam_encoder": (stage_ms(lambda: model.sam_encode(sam)), 5.961e12),
+                  "llm_prefill_S320": (stage_ms(lambda: model.llm_forward(emb)), 4.20e12),
+                  "clip_tower_projector": (stage_ms(lambda: model.encode_images(clip)), 1.574e11)}
+            res["mfma_stages"] = {k: dict(ms=round(ms, 3), tflops=round(fl / ms / 1e9, 1),
+                                          frac_of_mfma_peak=round(fl / ms / 1e9 / PEAK_BF16_TFLOPS, 4)) for k, (ms, fl) in st.items()}
+            res["mfma_stages"]["note"] = ("each stage alone on the chip through its C-ABI entry (sam_encode / llm_forward / encode_images, "
+                                          "5 calls after 2 warm-ups, host-timed); SAM encoder operands f16, LLaMA / CLIP bf16")
         ctx = dict(cfg=cfg, sd=sd, model=model, clip=clip, sam=sam, ids=ids, sizes=sizes, H=H, W=W, B=B, mode=mode)
         return res, ctx
 
