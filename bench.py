@@ -230,8 +230,14 @@ def main():
             return out
 
         roofline = None
-        rows = stamp_pass(roofline_steps) if dom and dom.startswith("gemv") and roofline_steps > 0 else []
-        if rows:
+        # (every rank runs the same passes whatever it finds dominant: the steps contain collectives)
+        rows, iso_rows = [], []
+        if roofline_steps > 0:
+            rows = stamp_pass(roofline_steps)
+            model.set_overlap(False)
+            iso_rows = stamp_pass(1)
+            model.set_overlap(True)
+        if rows and iso_rows and dom and dom.startswith("gemv"):
             situ = by_tag(rows)
             tot_us, tot_n, tot_b = (sum(v[f] for v in situ.values()) for f in ("us", "count", "bytes"))
             ach = tot_b / 1e9 / (tot_us / 1e6)
@@ -255,9 +261,6 @@ def main():
                 roofline["gap_between_launches_us"] = dict(median=round(gaps[len(gaps) // 2], 2),
                                                            p10=round(gaps[len(gaps) // 10], 2),
                                                            p90=round(gaps[len(gaps) * 9 // 10], 2))
-            model.set_overlap(False)
-            iso_rows = stamp_pass(1)
-            model.set_overlap(True)
             iso = by_tag(iso_rows)
             iu, inn, ib = (sum(v[f] for v in iso.values()) for f in ("us", "count", "bytes"))
             roofline["isolated"] = {
