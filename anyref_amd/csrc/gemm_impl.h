@@ -875,7 +875,9 @@ void launch_gemm(const GemmArgs& a_in, hipStream_t s) {
         ProfScope prof(is_half16<T>::value ? tagt : tag, flops, bytes, s);
         dim3 grid(cdiv(a.N, BN) * cdiv(a.M, BM), 1, a.batch);
         if constexpr (BM <= 256 && BM >= 128) {  // the SAM encoder's tiles
-          const int cap = a.max_wg / 8 * 8;
+          // (tiles small enough for two workgroups per CU -- 128 x 128 on two stages: 64 KB -- take twice the cap: the
+          // share is meant in CUs)
+          const int cap = a.max_wg / 8 * 8 * (lds * 2 <= 160 * 1024 ? 2 : 1);
           if (cap >= 8 && a.batch == 1 && (int)grid.x > cap) {
             if constexpr (BM == 256) {
               // the 256-row tiles sit at the register limit (256 x 320: 104 fragment + 160 accumulator registers): the
