@@ -651,6 +651,203 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const int bx, const
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// SAM global attention (4096 x 4096 tokens, head dim 80, decomposed rel-pos bias from the P buffer), 16-bit only: the
+// body above with TWO query blocks per wave (32 queries) -- every K fragment read from LDS feeds two MFMAs, every
+// transposed V block two, the softmax of one block is independent work beside the other block's MFMAs (a wave with
+// one block runs QK^T -> softmax -> P V as one dependent chain and its SIMD partner, aligned by the tile barriers, does
+// the same phase at the same time: MFMA pipe 19 % busy, 48 % of the wave cycles parked), and the tile barriers /
+// K / V staging are paid once per 32 queries.  The kw term of the bias (key tile = one row of the 64 x 64 grid) sits
+// in registers for the whole kernel, loaded straight from P; the kh term is one LDS word per tile and block.
+// Requirements (attn_launch): kw == 64 == BKV, Sk == kh * kw, Sq % (32 NWV) == 0, no masks, bias from rel_p.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int HD, int NWV>
+__device__ __forceinline__ void attn_g2_body(const AttnArgs& a, const int bx, const int by, const int bz, char* smem) {
+  static_assert(sizeof(T) == 2 && HD == 80, "16-bit, head dim 80");
+  using M_ = AMma<T>;
+  constexpr int NT = NWV * 64, QB = 2, BKV = 64, BQ = 16 * QB * NWV;
+  constexpr int KS = 32, VEC = 8, HDK = 96, LDK = HDK + VEC;
+  constexpr int LDV = ((HD * 2 + 255) / 256 * 256 + 32) / 2;
+  constexpr int NB = BKV / 16, DB = HD / 16;
+  T* Ks = reinterpret_cast<T*>(smem);
+  T* Vs = Ks + BKV * LDK;
+  float* relh_s = reinterpret_cast<float*>(Vs + BKV * LDV);
+  const int RH = a.kh + 1;  // row stride of relh_s (odd: the 16 queries of a lane group read 16 banks)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int qi = lane & 15, g = lane >> 4;
+  const int b = bz, h = by, q0 = bx * BQ;
+  const T* Qb = reinterpret_cast<const T*>(a.Q) + (int64_t)b * a.q_bs + (int64_t)h * a.q_hs;
+  const T* Kb = reinterpret_cast<const T*>(a.K) + (int64_t)b * a.k_bs + (int64_t)h * a.k_hs;
+  const T* Vb = reinterpret_cast<const T*>(a.V) + (int64_t)b * a.v_bs + (int64_t)h * a.v_hs;
+  constexpr float LOG2E = 1.4426950408889634f;
+  const float* P = a.rel_p + (int64_t)h * a.rel_hs + ((int64_t)b * a.Sq + q0) * a.rel_ld;
+  const int np = a.rel_ld / 2;
+
+  int il[QB];
+  short8 qf[QB][HDK / KS];
+  float relw_reg[QB][NB][4];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    il[qb] = (wave * QB + qb) * 16 + qi;
+    const T* qrow = Qb + (int64_t)(q0 + il[qb]) * a.q_rs;
+#pragma unroll
+    for (int kk = 0; kk < HDK / KS; ++kk) qf[qb][kk] = M_::glb(qrow, kk * KS, lane, true, HD);
+    const int x = (q0 + il[qb]) % a.kw;
+    const float* pw = P + (int64_t)il[qb] * a.rel_ld + np + x + a.kw - 1;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) relw_reg[qb][nb][r] = pw[-(nb * 16 + 4 * g + r)] * LOG2E;
+  }
+  for (int i = tid; i < BQ * a.kh; i += NT) {
+    const int r = i / a.kh, c = i - r * a.kh;
+    const int y = (q0 + r) / a.kw;
+    relh_s[r * RH + c] = P[(int64_t)r * a.rel_ld + (y - c + a.kh - 1)] * LOG2E;
+  }
+
+  float m_run[QB], l_run[QB];
+  float4v ot[QB][DB];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    m_run[qb] = -INFINITY;
+    l_run[qb] = 0.f;
+#pragma unroll
+    for (int d = 0; d < DB; ++d) ot[qb][d] = float4v{0.f, 0.f, 0.f, 0.f};
+  }
+
+  constexpr int KVEC = HDK / VEC, VVEC = HD / VEC;
+  constexpr int KPT = (BKV * KVEC + NT - 1) / NT, VPT = (BKV * VVEC + NT - 1) / NT;
+  uint4v kreg[KPT], vreg[VPT];
+  auto gload_tile = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+      const int v = tid + i * NT, row = v / KVEC, d = (v % KVEC) * VEC;
+      kreg[i] = (v < BKV * KVEC && d < HD) ? *reinterpret_cast<const uint4v*>(Kb + (int64_t)(kt + row) * a.k_rs + d)
+                                           : uint4v{0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+      const int v = tid + i * NT, row = v / VVEC, d = (v % VVEC) * VEC;
+      vreg[i] = v < BKV * VVEC ? *reinterpret_cast<const uint4v*>(Vb + (int64_t)(kt + row) * a.v_rs + d) : uint4v{0, 0, 0, 0};
+    }
+  };
+  auto sstore_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+      const int v = tid + i * NT, row = v / KVEC, d = (v % KVEC) * VEC;
+      if (v < BKV * KVEC) *reinterpret_cast<uint4v*>(&Ks[row * LDK + d]) = kreg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+      const int v = tid + i * NT, row = v / VVEC, d = (v % VVEC) * VEC;
+      if (v < BKV * VVEC) *reinterpret_cast<uint4v*>(&Vs[row * LDV + d]) = vreg[i];
+    }
+  };
+  gload_tile(0);
+  const float c1 = a.scale * LOG2E;
+  const uint32_t vbase = (uint32_t)(reinterpret_cast<const char*>(Vs) - smem) +
+                         (uint32_t)((4 * g + (qi >> 2)) * LDV + 4 * (qi & 3)) * 2u;
+  for (int kt = 0; kt < a.Sk; kt += BKV) {
+    sstore_tile();
+    __syncthreads();  // (also orders the relh_s fill before its first read)
+    if (kt + BKV < a.Sk) gload_tile(kt + BKV);
+    // ---- S^T = K Q^T for both blocks: one K fragment read, two MFMAs ----
+    float4v st[QB][NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) st[qb][nb] = float4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < HDK / KS; ++kk) {
+        const short8 kf = M_::lds(&Ks[(nb * 16 + qi) * LDK + kk * KS], lane);
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) st[qb][nb] = M_::mma(kf, qf[qb][kk], st[qb][nb]);
+      }
+    }
+    // ---- column softmax per block (log2 domain, lazy rescaling as in attn_body) ----
+    uint2v pb[QB][NB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      const float relh_tile = relh_s[il[qb] * RH + kt / BKV];
+      float sv[NB][4];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float sc = fmaf(st[qb][nb][r], c1, relh_tile + relw_reg[qb][nb][r]);
+          sv[nb][r] = sc;
+          mx = fmaxf(mx, sc);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = mx > m_run[qb] + 8.f ? mx : m_run[qb];
+      const bool moved = m_new != m_run[qb];
+      const float mref = m_new == -INFINITY ? 0.f : m_new;
+      if (__builtin_amdgcn_ballot_w64(moved) != 0) {
+        const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - mref);
+        l_run[qb] *= alpha;
+#pragma unroll
+        for (int d = 0; d < DB; ++d) ot[qb][d] *= alpha;
+        m_run[qb] = m_new;
+      }
+      float rs = 0.f;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          sv[nb][r] = __builtin_amdgcn_exp2f(sv[nb][r] - mref);
+          rs += sv[nb][r];
+        }
+        pb[qb][nb] = uint2v{pack2_from_f32<T>(sv[nb][0], sv[nb][1]), pack2_from_f32<T>(sv[nb][2], sv[nb][3])};
+      }
+      l_run[qb] += rs;
+    }
+    // ---- O^T += V^T P^T: one transposed V block read, two MFMAs ----
+#pragma unroll
+    for (int nb = 0; nb < NB; nb += 2) {
+      uint2v vt0[DB], vt1[DB];
+      lds_tr_blocks2<DB>(vbase + (uint32_t)(nb * 16 * LDV * 2), vbase + (uint32_t)((nb + 1) * 16 * LDV * 2), vt0, vt1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) {
+#pragma unroll
+        for (int d = 0; d < DB; ++d)
+          ot[qb][d] = mfma_16x16x16<T>(__builtin_bit_cast(short4v, vt0[d]), __builtin_bit_cast(short4v, pb[qb][nb]), ot[qb][d]);
+#pragma unroll
+        for (int d = 0; d < DB; ++d)
+          ot[qb][d] = mfma_16x16x16<T>(__builtin_bit_cast(short4v, vt1[d]), __builtin_bit_cast(short4v, pb[qb][nb + 1]), ot[qb][d]);
+      }
+    }
+    __syncthreads();  // K / V tile free for the next iteration
+  }
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    float l = l_run[qb];
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = l > 0.f ? 1.f / l : 0.f;
+    const int64_t off = (int64_t)b * a.o_bs + (int64_t)h * a.o_hs + (int64_t)(q0 + il[qb]) * a.o_rs;
+#pragma unroll
+    for (int d = 0; d < DB; ++d) {
+      const float4v v = ot[qb][d] * inv;
+      const int c = d * 16 + 4 * g;
+      if (a.o_f32) *reinterpret_cast<float4v*>(reinterpret_cast<float*>(a.O) + off + c) = v;
+      else store4_from_f32<T>(reinterpret_cast<T*>(a.O) + off + c, v[0], v[1], v[2], v[3]);
+    }
+  }
+}
+template <typename T, int HD, int NWV>
+__global__ __launch_bounds__(NWV * 64, 2) void attn_g2_kernel(AttnArgs a, int gx, int gy, int total) {  // 2 waves per SIMD
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // plain launch: gridDim.x == total; capped (AttnArgs::max_wg): every workgroup walks v, v + gridDim.x, ...
+  for (int v = blockIdx.x; v < total; v += gridDim.x) {
+    attn_g2_body<T, HD, NWV>(a, v % gx, (v / gx) % gy, v / (gx * gy), smem);
+    __syncthreads();
+  }
+}
+
 template <typename T, int HD, int NWV = 4, int BKV_ = 0, int NRES = 0>
 __global__ __launch_bounds__(NWV * 64) void attn_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -822,6 +1019,26 @@ static void attn_launch_cfg(const AttnArgs& a_in, hipStream_t s) {
   }
 }
 
+template <typename T, int HD, int NWV>
+static void attn_g2_launch(const AttnArgs& a, hipStream_t s) {
+  constexpr int BQ = 32 * NWV, LDK = 96 + 8, LDV = ((HD * 2 + 255) / 256 * 256 + 32) / 2;
+  const size_t lds = sizeof(T) * 64 * (LDK + LDV) + sizeof(float) * BQ * (a.kh + 1);
+  auto kern = &attn_g2_kernel<T, HD, NWV>;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  const int gx = a.Sq / BQ, gy = a.H, total = gx * gy * a.B;
+  static const std::string tag = std::string(is_half16<T>::value ? "attn_f16_hd" : "attn_bf16_hd") + std::to_string(HD) + "_g2w" +
+                                 std::to_string(NWV);
+  const double flops = 4.0 * a.B * a.H * (double)a.Sq * a.Sk * HD;
+  const double bytes = (double)a.B * a.H * HD * sizeof(T) * (2.0 * a.Sq + 2.0 * a.Sk);
+  ProfScope prof(tag.c_str(), flops, bytes, s);
+  const int grid = a.max_wg > 0 && total > a.max_wg ? a.max_wg : total;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NWV * 64), lds, s, a, gx, gy, total);
+}
+
 template <typename T, int HD>
 static void attn_launch(const AttnArgs& a, hipStream_t s) {
   // SAM windows (14 x 14 = 196 tokens, bf16, head dim 80): one workgroup of 13 waves per (window, head) with all
@@ -836,6 +1053,21 @@ static void attn_launch(const AttnArgs& a, hipStream_t s) {
     if (a.Sq == a.Sk && a.Sq > 192 && a.Sq <= 240 && !a.causal) {
       attn_launch_cfg<T, HD, 7, 80>(a, s);
       return;
+    }
+    // SAM global attention with the bias in the P buffer and one 64-key tile per grid row: two query blocks per wave
+    if (a.Sq >= 1024 && !a.causal && a.rel_p && a.kw == 64 && a.kh * a.kw == a.Sk && a.Sq == a.Sk && !a.kv_len && !a.q_len &&
+        !a.q_pos0 && a.o_rs % 4 == 0 && a.o_hs % 4 == 0 && a.o_bs % 4 == 0) {
+      // (lab knob: 0 = the general kernel below, 4 / 8 waves; SAM-H, 16 heads, scratch/bench_attn_global.py: 314 us general,
+      // 195 us with 4 waves -- two workgroups per CU --, 186 us with 8)
+      static const int g2 = getenv("ANYREF_ATTN_G2") ? atoi(getenv("ANYREF_ATTN_G2")) : 8;
+      if (g2 == 4 && a.Sq % 128 == 0) {
+        attn_g2_launch<T, HD, 4>(a, s);
+        return;
+      }
+      if (g2 == 8 && a.Sq % 256 == 0) {
+        attn_g2_launch<T, HD, 8>(a, s);
+        return;
+      }
     }
     // SAM global attention (4096 tokens): 8 waves share each K/V tile (128 queries per workgroup): 337 -> 311 us;
     // 6 waves 435 us, 4 waves (the default below) 337 us

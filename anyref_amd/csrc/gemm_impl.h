@@ -160,6 +160,64 @@ __device__ __forceinline__ void gemm_epilogue_ct(const GemmArgs& a, float4v (&ac
     const int m = mrow0 + i * 16 + (lane & 15);
     dms[i] = m < a.M ? (a.row_map ? a.row_map[m] : m) : -1;
   }
+  if constexpr (VEC) {
+    // LEAN: the 256 x 320 tile holds 160 accumulator registers -- no column-scale vectors (that case takes the
+    // per-fragment path below) and the residual rows are not loaded a row ahead (with them the epilogue spilled 124 bytes)
+    constexpr bool LEAN = MI * NI * 4 > 128;
+    if (!a.swiglu_pairs && !(LEAN && a.col_scale)) {
+      // The common epilogue in PHASES.  Written per fragment (epi_store4) the compiler emitted, for each of the MI x NI
+      // fragments, a bias load -> s_waitcnt vmcnt(0) -> (residual load -> s_waitcnt vmcnt(0)) -> store chain behind run-time
+      // flag branches: 32-40 dependent round trips per wave (bias alone: SAM qkv 46.5 -> 49.3 us, fc1 61.8 -> 66.7 us).
+      // Here a lane's NI bias / column-scale vectors are loaded ONCE (they do not depend on the row), and each fragment
+      // row issues its NI residual loads together, one row ahead of the row being converted and stored.
+      int ns[NI];
+      float4v bv[NI], sv[LEAN ? 1 : NI];
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        ns[j] = ncol0 + j * 16 + 4 * (lane >> 4);
+        const bool in = ns[j] < a.N;
+        bv[j] = bias && in ? *reinterpret_cast<const float4v*>(bias + ns[j]) : float4v{0.f, 0.f, 0.f, 0.f};
+        if constexpr (!LEAN) {
+          sv[j] = a.col_scale && in ? *reinterpret_cast<const float4v*>(a.col_scale + ns[j]) : float4v{1.f, 1.f, 1.f, 1.f};
+          sv[j] *= a.alpha;
+        }
+      }
+      float4v rv[LEAN ? 1 : 2][NI];
+      auto load_resid = [&](auto i_c, float4v (&r)[NI]) {
+        constexpr int i = decltype(i_c)::value;
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          r[j] = resid && dms[i] >= 0 && ns[j] < a.N ? *reinterpret_cast<const float4v*>(resid + (int64_t)dms[i] * a.ldr + ns[j])
+                                                      : float4v{0.f, 0.f, 0.f, 0.f};
+      };
+      if constexpr (!LEAN) load_resid(std::integral_constant<int, 0>(), rv[0]);
+      static_for(std::make_integer_sequence<int, MI>{}, [&](auto i_c) {
+        constexpr int i = decltype(i_c)::value, cur = LEAN ? 0 : (i & 1);
+        if constexpr (LEAN) load_resid(i_c, rv[0]);
+        else if constexpr (i + 1 < MI) load_resid(std::integral_constant<int, i + 1>(), rv[(i + 1) & 1]);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          if (dms[i] >= 0 && ns[j] < a.N) {
+            float4v v;
+            if constexpr (LEAN) v = acc[i][j] * a.alpha + bv[j];
+            else v = acc[i][j] * sv[j] + bv[j];
+            v = float4v{act_ct<ACT, sizeof(T) == 2>(v[0]), act_ct<ACT, sizeof(T) == 2>(v[1]), act_ct<ACT, sizeof(T) == 2>(v[2]),
+                        act_ct<ACT, sizeof(T) == 2>(v[3])};
+            v += rv[cur][j];
+            const int64_t off = (int64_t)dms[i] * a.ldc + ns[j];
+            if (a.c_f32) {
+              *reinterpret_cast<float4v*>(Cf + off) = v;
+            } else if constexpr (sizeof(T) == 2) {
+              *reinterpret_cast<uint2*>(Ct + off) = make_uint2(pack2_from_f32<T>(v[0], v[1]), pack2_from_f32<T>(v[2], v[3]));
+            } else {
+              *reinterpret_cast<float4v*>(Ct + off) = v;
+            }
+          }
+        }
+      });
+      return;
+    }
+  }
   static_for(std::make_integer_sequence<int, MI * NI>{}, [&](auto ij) {
     constexpr int i = decltype(ij)::value / NI, j = decltype(ij)::value % NI;
     const int n = ncol0 + j * 16 + 4 * (lane >> 4);

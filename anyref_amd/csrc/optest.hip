@@ -93,6 +93,21 @@ int anyref_op_attention_tab(int t, void* stream, const void* q, const void* k, c
   });
 }
 
+int anyref_op_attention_relp(int t, void* stream, const void* q, const void* k, const void* v, void* o, int B, int H, int S,
+                             int hd, float scale, const float* rel_p, int rel_ld, int kh, int kw) {
+  OP_GUARD({
+    AttnArgs a;
+    a.Q = q; a.K = k; a.V = v; a.O = o;
+    a.q_bs = a.k_bs = a.v_bs = a.o_bs = (int64_t)S * H * hd;
+    a.q_rs = a.k_rs = a.v_rs = a.o_rs = H * hd; a.q_hs = a.k_hs = a.v_hs = a.o_hs = hd;
+    a.B = B; a.H = H; a.Sq = S; a.Sk = S; a.hd = hd; a.scale = scale;
+    a.rel_p = rel_p; a.rel_ld = rel_ld; a.rel_hs = (int64_t)B * S * rel_ld; a.kh = kh; a.kw = kw;
+    if (t == 0) launch_attention<float>(a, (hipStream_t)stream);
+    else if (t == 2) launch_attention<f16>(a, (hipStream_t)stream);
+    else launch_attention<bf16>(a, (hipStream_t)stream);
+  });
+}
+
 int anyref_op_rel_pos(int t, void* stream, const void* q, const float* tab_h, const float* tab_w, int B, int H,
                       int size, int hd, float* rel_h, float* rel_w) {
   OP_GUARD({

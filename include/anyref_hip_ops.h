@@ -90,6 +90,12 @@ int anyref_op_kaldi_fbank(void* stream, const float* wave, int C, int T, int win
  * takes (hd 80, 192 < S <= 208); others are refused. */
 int anyref_op_attention_tab(int t, void* stream, const void* q, const void* k, const void* v, void* o, int B, int H, int S,
                             int hd, float scale, const void* tab_h, const void* tab_w, int tab_ld, int kh, int kw);
+/* the same attention with the bias taken from the P buffer the model's batched rel-pos GEMM writes (model.hip
+ * sam_encoder, image_encoder.py:354-392): P f32 [H][B*S][rel_ld], columns [0, rel_ld/2) = q . rel_pos_h[e],
+ * [rel_ld/2, rel_ld) = q . rel_pos_w[e]; the kernel applies the get_rel_pos shift.  S = kh*kw tokens, [B,S,H,hd]
+ * operands.  kw == 64 (SAM global attention) takes the two-query-blocks-per-wave kernel. */
+int anyref_op_attention_relp(int t, void* stream, const void* q, const void* k, const void* v, void* o, int B, int H, int S,
+                             int hd, float scale, const float* rel_p, int rel_ld, int kh, int kw);
 /* Sam.postprocess_masks on low [n,lh,lw] f32 */
 int anyref_op_postprocess(void* stream, const float* low, int n, int lh, int lw, int S, int rh, int rw, int H,
                           int W, float* out);

@@ -237,6 +237,35 @@ def test_sam_attention_rel_pos(lib, ty, B, H, size, hd):
 
 
 @pytest.mark.parametrize("ty", [1, 2])
+@pytest.mark.parametrize("B,H,size", [(1, 2, 64), (2, 3, 64), (1, 2, 32)])
+def test_sam_global_attention_bias_from_p(lib, B, H, size, ty):
+    """SAM global attention as the encoder runs it (image_encoder.py:231-260, 354-392): the bias comes from the P buffer
+    of the batched rel-pos GEMM (q . rel_pos_h / rel_pos_w for every table row), the kernel applies the get_rel_pos shift.
+    size 64 = SAM-H's 4096 tokens: the two-query-blocks-per-wave kernel; size 32: the general one."""
+    hd = 80
+    g = torch.Generator().manual_seed(B * 11 + H + size)
+    S = size * size
+    q, k, v = (torch.randn(B, S, H, hd, generator=g) for _ in range(3))
+    th, tw = torch.randn(2 * size - 1, hd, generator=g) * 0.3, torch.randn(2 * size - 1, hd, generator=g) * 0.3
+    idx = torch.arange(size)[:, None] - torch.arange(size)[None, :] + size - 1
+    qr = rnd(q, ty)
+    rq = qr.permute(0, 2, 1, 3).reshape(B, H, size, size, hd)
+    rel_h = torch.einsum("bnhwc,hkc->bnhwk", rq, th[idx]).reshape(B, H, S, size)
+    rel_w = torch.einsum("bnhwc,wkc->bnhwk", rq, tw[idx]).reshape(B, H, S, size)
+    scale = hd ** -0.5
+    ref = ref_attention(qr, rnd(k, ty), rnd(v, ty), scale, False, None, rel_h, rel_w, size)
+    npad = 2 * size
+    p = torch.zeros(H, B * S, 2 * npad)
+    qh = qr.permute(2, 0, 1, 3).reshape(H, B * S, hd)
+    p[:, :, : 2 * size - 1] = qh @ th.t()
+    p[:, :, npad: npad + 2 * size - 1] = qh @ tw.t()
+    o = torch.empty(B, S, H, hd, device="cuda", dtype=_DT[ty])
+    check(lib, lib.anyref_op_attention_relp(ty, None, P(dev(q, ty)), P(dev(k, ty)), P(dev(v, ty)), P(o), B, H, S, hd, scale,
+                                            P(p.cuda().contiguous()), 2 * npad, size, size))
+    close(o, ref, 3e-2 if ty == 1 else 4e-3)
+
+
+@pytest.mark.parametrize("ty", [1, 2])
 @pytest.mark.parametrize("B,H", [(1, 1), (5, 3)])
 def test_sam_window_attention_bias_from_tables(lib, B, H, ty):
     """SAM-H windows (14 x 14, hd 80, bf16 / f16): the kernel computes q . R^T itself from the rel-pos tables and applies
