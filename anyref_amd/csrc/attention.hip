@@ -369,7 +369,10 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const int bx, const
     kt_begin = split * chunk;
     kv_end = kv_end < kt_begin + chunk ? kv_end : kt_begin + chunk;
   }
-  if constexpr (NRES > 0 && HD == 64) {
+#ifndef ANYREF_ATTN_RES80_ONESHOT
+#define ANYREF_ATTN_RES80_ONESHOT 0  // lab build flag: SAM windows with the CLIP form's one-shot request (36.9 vs 36.4 us: off)
+#endif
+  if constexpr (NRES > 0 && (HD == 64 || (HD == 80 && ANYREF_ATTN_RES80_ONESHOT))) {
     // short rows (CLIP): every resident tile requested before the first LDS store -- one round trip, not NRES
     uint4v kall[NRES][KPT], vall[NRES][VPT];
 #pragma unroll
@@ -397,6 +400,10 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const int bx, const
         sstore_tile(t);
       }
     __syncthreads();
+  } else {
+    if (kv_end > kt_begin) gload_tile(kt_begin);
+  }
+  if constexpr (NRES > 0) {
     if constexpr (BF) {
       if (rel_tab) {
         // P^T[entry][query] = R q^T for both tables: entry = 16 blk + 4 g + r, query = this lane's column; the
@@ -428,8 +435,6 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const int bx, const
         __syncthreads();
       }
     }
-  } else {
-    if (kv_end > kt_begin) gload_tile(kt_begin);
   }
   float relw_pad[4] = {0.f, 0.f, 0.f, 0.f};  // rowpad: the kw term of this lane's four key columns (-inf: padding)
   if (rowpad) {

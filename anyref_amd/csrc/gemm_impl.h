@@ -145,7 +145,19 @@ __device__ __forceinline__ void epi_store4(const GemmArgs& a, const float* bias,
   }
 }
 
-template <typename T, int MI, int NI, int ACT, bool VEC>
+// PAIRED (the LDS-DMA kernel, 16-bit weights): fragments 2p and 2p + 1 of a wave hold INTERLEAVED column groups of
+// the 32 columns they share -- lane group g owns columns 8g .. 8g+3 in fragment 2p and 8g+4 .. 8g+7 in fragment 2p + 1
+// (the kernel feeds the MFMA the weight rows in that order: a pure LDS address permutation) -- so a lane holds EIGHT
+// consecutive output columns of a row and a 16-bit tile leaves as 16-byte stores: half the store instructions, each
+// covering 16 rows x 64 contiguous bytes.  The store tail is bound by the number of (instruction, row) write requests,
+// not by bytes (a 4096 x 3840 tile set: 9.2 us of a 16.2 us K = 64 launch, the same for f16 and f32 outputs).
+template <int NI, bool PAIRED>
+__device__ __forceinline__ int frag_col(int j, int lane) {  // first of the 4 consecutive columns fragment j holds, tile-relative
+  if (PAIRED && j < (NI & ~1)) return (j >> 1) * 32 + 8 * (lane >> 4) + 4 * (j & 1);
+  return j * 16 + 4 * (lane >> 4);
+}
+
+template <typename T, int MI, int NI, int ACT, bool VEC, bool PAIRED = false>
 __device__ __forceinline__ void gemm_epilogue_ct(const GemmArgs& a, float4v (&acc)[MI][NI], int mrow0, int ncol0, int z,
                                                  int lane) {
   const float* bias = a.bias ? a.bias + (int64_t)z * a.sBias : nullptr;
@@ -174,7 +186,7 @@ __device__ __forceinline__ void gemm_epilogue_ct(const GemmArgs& a, float4v (&ac
       float4v bv[NI], sv[LEAN ? 1 : NI];
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
-        ns[j] = ncol0 + j * 16 + 4 * (lane >> 4);
+        ns[j] = ncol0 + frag_col<NI, PAIRED>(j, lane);
         const bool in = ns[j] < a.N;
         bv[j] = bias && in ? *reinterpret_cast<const float4v*>(bias + ns[j]) : float4v{0.f, 0.f, 0.f, 0.f};
         if constexpr (!LEAN) {
@@ -182,6 +194,8 @@ __device__ __forceinline__ void gemm_epilogue_ct(const GemmArgs& a, float4v (&ac
           sv[j] *= a.alpha;
         }
       }
+      // 16-byte stores of a fragment pair: rows 16-byte aligned and the pair never split by the N edge
+      const bool pair16 = PAIRED && a.N % 8 == 0 && a.ldc % 8 == 0 && a.sC % 8 == 0 && !((uintptr_t)a.C & 15);
       float4v rv[LEAN ? 1 : 2][NI];
       auto load_resid = [&](auto i_c, float4v (&r)[NI]) {
         constexpr int i = decltype(i_c)::value;
@@ -195,22 +209,35 @@ __device__ __forceinline__ void gemm_epilogue_ct(const GemmArgs& a, float4v (&ac
         constexpr int i = decltype(i_c)::value, cur = LEAN ? 0 : (i & 1);
         if constexpr (LEAN) load_resid(i_c, rv[0]);
         else if constexpr (i + 1 < MI) load_resid(std::integral_constant<int, i + 1>(), rv[(i + 1) & 1]);
+        float4v vv[NI];
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          float4v v;
+          if constexpr (LEAN) v = acc[i][j] * a.alpha + bv[j];
+          else v = acc[i][j] * sv[j] + bv[j];
+          v = float4v{act_ct<ACT, sizeof(T) == 2>(v[0]), act_ct<ACT, sizeof(T) == 2>(v[1]), act_ct<ACT, sizeof(T) == 2>(v[2]),
+                      act_ct<ACT, sizeof(T) == 2>(v[3])};
+          vv[j] = v + rv[cur][j];
+        }
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
           if (dms[i] >= 0 && ns[j] < a.N) {
-            float4v v;
-            if constexpr (LEAN) v = acc[i][j] * a.alpha + bv[j];
-            else v = acc[i][j] * sv[j] + bv[j];
-            v = float4v{act_ct<ACT, sizeof(T) == 2>(v[0]), act_ct<ACT, sizeof(T) == 2>(v[1]), act_ct<ACT, sizeof(T) == 2>(v[2]),
-                        act_ct<ACT, sizeof(T) == 2>(v[3])};
-            v += rv[cur][j];
             const int64_t off = (int64_t)dms[i] * a.ldc + ns[j];
             if (a.c_f32) {
-              *reinterpret_cast<float4v*>(Cf + off) = v;
+              *reinterpret_cast<float4v*>(Cf + off) = vv[j];
             } else if constexpr (sizeof(T) == 2) {
-              *reinterpret_cast<uint2*>(Ct + off) = make_uint2(pack2_from_f32<T>(v[0], v[1]), pack2_from_f32<T>(v[2], v[3]));
+              if constexpr (PAIRED) {
+                if (j < (NI & ~1) && pair16) {  // (N % 8 == 0: the pair is in range together)
+                  if ((j & 1) == 0)
+                    *reinterpret_cast<uint4v*>(Ct + off) =
+                        uint4v{pack2_from_f32<T>(vv[j][0], vv[j][1]), pack2_from_f32<T>(vv[j][2], vv[j][3]),
+                               pack2_from_f32<T>(vv[j | 1][0], vv[j | 1][1]), pack2_from_f32<T>(vv[j | 1][2], vv[j | 1][3])};
+                  continue;
+                }
+              }
+              *reinterpret_cast<uint2*>(Ct + off) = make_uint2(pack2_from_f32<T>(vv[j][0], vv[j][1]), pack2_from_f32<T>(vv[j][2], vv[j][3]));
             } else {
-              *reinterpret_cast<float4v*>(Ct + off) = v;
+              *reinterpret_cast<float4v*>(Ct + off) = vv[j];
             }
           }
         }
@@ -220,30 +247,30 @@ __device__ __forceinline__ void gemm_epilogue_ct(const GemmArgs& a, float4v (&ac
   }
   static_for(std::make_integer_sequence<int, MI * NI>{}, [&](auto ij) {
     constexpr int i = decltype(ij)::value / NI, j = decltype(ij)::value % NI;
-    const int n = ncol0 + j * 16 + 4 * (lane >> 4);
+    const int n = ncol0 + frag_col<NI, PAIRED>(j, lane);
     if (dms[i] >= 0 && n < a.N) epi_store4<T, ACT, VEC>(a, bias, resid, Cf, Ct, dms[i], n, acc[i][j] * a.alpha);
   });
 }
 
 // mrow0 / ncol0: first output row / column of this WAVE's sub-tile (MI x NI fragments of 16 x 16)
-template <typename T, int MI, int NI>
+template <typename T, int MI, int NI, bool PAIRED = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, float4v (&acc)[MI][NI], int mrow0, int ncol0, int z,
                                               int lane) {
   if (a.vec_ok) {
     switch (a.act) {
-      case ACT_NONE: gemm_epilogue_ct<T, MI, NI, ACT_NONE, true>(a, acc, mrow0, ncol0, z, lane); break;
-      case ACT_RELU: gemm_epilogue_ct<T, MI, NI, ACT_RELU, true>(a, acc, mrow0, ncol0, z, lane); break;
-      case ACT_GELU: gemm_epilogue_ct<T, MI, NI, ACT_GELU, true>(a, acc, mrow0, ncol0, z, lane); break;
-      case ACT_QUICK_GELU: gemm_epilogue_ct<T, MI, NI, ACT_QUICK_GELU, true>(a, acc, mrow0, ncol0, z, lane); break;
-      default: gemm_epilogue_ct<T, MI, NI, ACT_SILU, true>(a, acc, mrow0, ncol0, z, lane); break;
+      case ACT_NONE: gemm_epilogue_ct<T, MI, NI, ACT_NONE, true, PAIRED>(a, acc, mrow0, ncol0, z, lane); break;
+      case ACT_RELU: gemm_epilogue_ct<T, MI, NI, ACT_RELU, true, PAIRED>(a, acc, mrow0, ncol0, z, lane); break;
+      case ACT_GELU: gemm_epilogue_ct<T, MI, NI, ACT_GELU, true, PAIRED>(a, acc, mrow0, ncol0, z, lane); break;
+      case ACT_QUICK_GELU: gemm_epilogue_ct<T, MI, NI, ACT_QUICK_GELU, true, PAIRED>(a, acc, mrow0, ncol0, z, lane); break;
+      default: gemm_epilogue_ct<T, MI, NI, ACT_SILU, true, PAIRED>(a, acc, mrow0, ncol0, z, lane); break;
     }
   } else {
     switch (a.act) {
-      case ACT_NONE: gemm_epilogue_ct<T, MI, NI, ACT_NONE, false>(a, acc, mrow0, ncol0, z, lane); break;
-      case ACT_RELU: gemm_epilogue_ct<T, MI, NI, ACT_RELU, false>(a, acc, mrow0, ncol0, z, lane); break;
-      case ACT_GELU: gemm_epilogue_ct<T, MI, NI, ACT_GELU, false>(a, acc, mrow0, ncol0, z, lane); break;
-      case ACT_QUICK_GELU: gemm_epilogue_ct<T, MI, NI, ACT_QUICK_GELU, false>(a, acc, mrow0, ncol0, z, lane); break;
-      default: gemm_epilogue_ct<T, MI, NI, ACT_SILU, false>(a, acc, mrow0, ncol0, z, lane); break;
+      case ACT_NONE: gemm_epilogue_ct<T, MI, NI, ACT_NONE, false, PAIRED>(a, acc, mrow0, ncol0, z, lane); break;
+      case ACT_RELU: gemm_epilogue_ct<T, MI, NI, ACT_RELU, false, PAIRED>(a, acc, mrow0, ncol0, z, lane); break;
+      case ACT_GELU: gemm_epilogue_ct<T, MI, NI, ACT_GELU, false, PAIRED>(a, acc, mrow0, ncol0, z, lane); break;
+      case ACT_QUICK_GELU: gemm_epilogue_ct<T, MI, NI, ACT_QUICK_GELU, false, PAIRED>(a, acc, mrow0, ncol0, z, lane); break;
+      default: gemm_epilogue_ct<T, MI, NI, ACT_SILU, false, PAIRED>(a, acc, mrow0, ncol0, z, lane); break;
     }
   }
 }
@@ -400,11 +427,30 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs a) {
   // last round that only waves 0 .. PW-1 take part in (128 x 160: 256 equal tiles for SAM fc2, 4096 x 1280)
   constexpr int RA = BM / (NW * 8), RWF = BN / (NW * WRPI), PW = (BN % (NW * WRPI)) / WRPI, RW = RWF + (PW > 0);
   constexpr int LPT = RA + RWF;                          // DMA instructions per lane per tile (+1 on waves < PW)
+  // 16-bit weights: the wave's W fragments come in PAIRS with interleaved rows (see frag_col above: lane i = 4 g' + r' of
+  // fragment 2p + q reads tile row 32 p + 8 g' + 4 q + r'), so the epilogue holds 8 consecutive columns per lane.  The W
+  // tile's chunk swizzle is keyed on the row bits that differ among those 16 rows (bit 1 and bits 3-4; rows 2k, 2k + 1
+  // already sit in different halves of the 256-byte bank row): conflict-free like (row >> 1) & 7 is for 16 consecutive
+  // rows (the A tile, and an odd last fragment -- 80-column waves -- which reads consecutive rows at 2-way conflicts).
+#ifdef ANYREF_GEMM_NO_PAIRW  // lab build: the unpaired fragment order
+  constexpr bool PAIRW = false;
+#else
+  // (not the 128 x 160 tile -- SAM fc2, f32 output: nothing to gain from 16-byte stores and its odd fifth fragment's
+  //  2-way conflicts cost 1.3 us of 61.6; on one box, unpaired -> paired: qkv 45.3 -> 41.6 us, fc1 62.6 -> 59.8, proj 20.8 -> 20.0)
+  constexpr bool PAIRW = !W8 && !(NI % 2 == 1 && BM < 256);
+#endif
+  constexpr int NIP = PAIRW ? (NI & ~1) : 0;  // fragments that come in pairs
   static_assert(BM % (NW * 8) == 0 && BN % WRPI == 0 && (PW == 0 || !W8), "tile rows must split over the waves");
   static_assert(NS >= 2 && NS <= 4 && (NS - 2) * (LPT + 1) <= 63, "stage count / vmcnt range");
   extern __shared__ __attribute__((aligned(1024))) char smem[];  // the ONLY LDS object (rule: one array)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave / WN, wc = wave % WN;
+  auto wswz = [](int row) { return PAIRW ? ((row >> 1) & 1) | (((row >> 3) & 3) << 1) : (row >> 1) & 7; };
+  // W tile row lane (l & 15) reads for the wave's fragment f
+  auto wrow = [&](int f) {
+    const int i = lane & 15;
+    return wc * TN + (f < NIP ? (f >> 1) * 32 + 8 * (i >> 2) + 4 * (f & 1) + (i & 3) : f * 16 + i);
+  };
   const int tiles_m = cdiv(a.M, BM), tiles_n = cdiv(a.N, BN), nwg = tiles_m * tiles_n;
   for (int vb = blockIdx.x; vb < nwg; vb += gridDim.x) {  // (one pass unless PERSIST: see the end of the body)
   int id = vb;
@@ -461,7 +507,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs a) {
       const int row = (r * NW + wave) * 8 + srow;
       int gn = n0 + row;
       gn = gn < a.N ? gn : a.N - 1;
-      wsrc[r] = W + (int64_t)gn * a.ldw + ((sp ^ ((row >> 1) & 7)) << 3);
+      wsrc[r] = W + (int64_t)gn * a.ldw + ((sp ^ wswz(row)) << 3);
     }
   }
   // The stage index is a compile-time constant (loop unrolled by two below): with a runtime index hipcc
@@ -516,8 +562,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs a) {
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int f = 0; f < NH0; ++f) {
-          const int row = wc * TN + f * 16 + (lane & 15), c = ks * 4 + (lane >> 4);
-          b0[ks][f] = *reinterpret_cast<const short8*>(Wb + row * ROWB + ((c ^ ((row >> 1) & 7)) << 4));
+          const int row = wrow(f), c = ks * 4 + (lane >> 4);
+          b0[ks][f] = *reinterpret_cast<const short8*>(Wb + row * ROWB + ((c ^ wswz(row)) << 4));
         }
     };
     auto ldw1 = [&]() {
@@ -525,8 +571,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs a) {
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int f = 0; f < NH1; ++f) {
-          const int row = wc * TN + (NH0 + f) * 16 + (lane & 15), c = ks * 4 + (lane >> 4);
-          b1[ks][f] = *reinterpret_cast<const short8*>(Wb + row * ROWB + ((c ^ ((row >> 1) & 7)) << 4));
+          const int row = wrow(NH0 + f), c = ks * 4 + (lane >> 4);
+          b1[ks][f] = *reinterpret_cast<const short8*>(Wb + row * ROWB + ((c ^ wswz(row)) << 4));
         }
     };
     auto mma = [&](auto i_c, auto j_c, const short8 (&af)[2][MH], const auto& bf) {
@@ -572,14 +618,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs a) {
       }
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
-        const int row = wc * TN + j * 16 + (lane & 15);
+        const int row = wrow(j);
         if constexpr (W8) {
           // k = 32 ks + 8 g .. + 7: the 8 bytes at chunk (2 ks + g / 2), half (g & 1) of the 64-byte row
           const int g = lane >> 4, c8 = ks * 2 + (g >> 1);
           bfr[j] = fp8x8_to_bf16x8(
               *reinterpret_cast<const uint2v*>(Wb + row * WROWB + ((c8 ^ ((row >> 2) & 3)) << 4) + ((g & 1) << 3)));
         } else {
-          bfr[j] = *reinterpret_cast<const short8*>(Wb + row * ROWB + ((c ^ ((row >> 1) & 7)) << 4));
+          bfr[j] = *reinterpret_cast<const short8*>(Wb + row * ROWB + ((c ^ wswz(row)) << 4));
         }
       }
 #pragma unroll
@@ -609,7 +655,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs a) {
       }
     });
   }
-  gemm_epilogue<T, MI, NI>(a, acc, m0 + wr * TM, n0 + wc * TN, z, lane);
+  gemm_epilogue<T, MI, NI, PAIRW>(a, acc, m0 + wr * TM, n0 + wc * TN, z, lane);
   if constexpr (!PERSIST) break;
   __syncthreads();  // every wave is done with this tile's LDS stages before the next tile's first DMA lands
   }
