@@ -327,6 +327,8 @@ static void gemv_dispatch(const GemvArgs& a_in, int b0, int nb, hipStream_t s) {
   // one or two 8-wave workgroups per CU depending on the LDS the activation stage needs
   // (512 workgroups measured best for N*K of 34-262 MB; 256 / 1024 / 2048 were 3-30 % slower)
   int grid = 256 * (lds > 76 * 1024 ? 1 : 2);
+  const int grid_rule = grid;  // (the wave-pair decision below goes by this one: the same sums whatever grid is asked for)
+  if (a.grid > 0 && a.grid < grid) grid = a.grid;
   if (gemv_grid_knob() > 0) grid = gemv_grid_knob();
   auto go = [&](auto xpt_tag) {
     constexpr int XPT = decltype(xpt_tag)::value;
@@ -354,7 +356,7 @@ static void gemv_dispatch(const GemvArgs& a_in, int b0, int nb, hipStream_t s) {
     // wave pairs where single waves would leave half of the grid without a row group (N = 4096 at 7B: o_proj 8.5 ->
     // 8.05 us, down_proj 17.45 -> 16.7 us); with more groups than waves the plain split is faster (qkv 17.9 vs 18.8 us,
     // gate/up 30.9 vs 31.6: the hand-off barrier per group costs more than the better balance returns)
-    const bool pair = gemv_pair_knob() && cdiv(a.N, a.W2 ? 1 : 2) * 2 <= grid * 8;
+    const bool pair = gemv_pair_knob() && cdiv(a.N, a.W2 ? 1 : 2) * 2 <= (gemv_grid_knob() > 0 ? grid : grid_rule) * 8;
     auto by_pair = [&](auto dual_t, auto w8_t) {
       if (pair) launch(dual_t, w8_t, TT());
       else launch(dual_t, w8_t, FF());

@@ -184,6 +184,7 @@ struct GemvArgs {
   const int* xn_row_map = nullptr;
   int xn_ld = 0;
   StampArgs stamp;  // filled by the launcher when kernel-side timestamps are on
+  int grid = 0;     // > 0: this many workgroups instead of the launcher's rule (decode steps beside the co-running encoder)
 };
 template <typename T>
 void launch_gemv(const GemvArgs& a, hipStream_t s);

@@ -236,8 +236,15 @@ class Model : public ModelBase {
     return fused;
   }
   // nn.Linear (or a row range of a fused one) as the weight operand of a decode GEMV
+  // Workgroups of the decode GEMVs in a step that runs beside the capped SAM encoder (0: the launcher's 512).  The encoder's
+  // 256-row GEMM workgroups take every VGPR of their CU, so only the ~128 free CUs hold GEMV workgroups (two each): the
+  // stamps show a 512-workgroup launch starting its second half 7 - 16 us late, one round behind the first.  With 256
+  // workgroups (one round on the free CUs) a co-running step takes 3.97 -> 3.85 ms (image 39.8 - 40.3 -> 39.5 - 40.1 on one
+  // box; 384 with the wave-pair kernels unbalanced: 4.1); alone 512 stays better (2.77 vs 2.89 ms).  Same sums either way.
+  int gemv_grid_ = 0;
   void gemv_w(GemvArgs& g, const Lin<T>& l, int row0 = 0) const {
     g.ldw = l.stride();
+    g.grid = gemv_grid_;
     if (l.w8) {
       g.W = l.w8 + (size_t)row0 * l.stride();
       g.wscale = l.ws + row0;
@@ -351,7 +358,7 @@ class Model : public ModelBase {
   bool sam_forked_ = false;
   // One decode step is ~170 launches whose arguments never change (position and next token live on
   // the device), so it is captured once per (batch, keep_q) and replayed as a hipGraph.
-  void decode_step_graph(hipStream_t s, int B, bool keep_q);
+  void decode_step_graph(hipStream_t s, int B, bool keep_q, bool corun = false);
   hipStream_t cap_stream_ = nullptr;
   std::map<int, hipGraphExec_t> decode_graphs_;
   int splice_inputs(hipStream_t s, const int64_t* input_ids, const int32_t* lens, int B, int Lmax,
@@ -1063,14 +1070,20 @@ void Model<T, TS>::sam_feed(int upto, bool capped) {
 }
 
 template <typename T, typename TS>
-void Model<T, TS>::decode_step_graph(hipStream_t s, int B, bool keep_q) {
+void Model<T, TS>::decode_step_graph(hipStream_t s, int B, bool keep_q, bool corun) {
+  static const int corun_grid = getenv("ANYREF_GEMV_CORUN_GRID") ? atoi(getenv("ANYREF_GEMV_CORUN_GRID")) : 256;  // lab knob
+  struct GridScope {  // the step's GEMV launches (eager or being captured) read gemv_grid_
+    int& g;
+    ~GridScope() { g = 0; }
+  } grid_scope{gemv_grid_};
+  gemv_grid_ = corun ? corun_grid : 0;
   if (!use_graphs_ || (g_prof && g_prof->on)) {  // the sampled profiler brackets kernels with events: eager
     llm_decode_step(s, B, keep_q);
     return;
   }
   // with kernel-side timestamps on, the step is a graph of its own: its GEMVs carry their stamp slots
   const bool stamped = stamp.on;
-  const int key = B * 4 + (keep_q ? 2 : 0) + (stamped ? 1 : 0);
+  const int key = B * 8 + (corun && corun_grid > 0 ? 4 : 0) + (keep_q ? 2 : 0) + (stamped ? 1 : 0);
   auto it = decode_graphs_.find(key);
   if (it == decode_graphs_.end()) {
     if (keep_q) ensure_q_last();
@@ -1860,13 +1873,21 @@ void Model<T, TS>::generate(hipStream_t s, const float* clip_images, const float
   bool early = !early_off_ && sam_forked_ && B == 1 && c.rephrase_weight <= 0.f;
   for (int i = 1; early && i < lens[0]; ++i)
     if (input_ids[i] >= c.seg_lo && input_ids[i] <= c.seg_hi) early = false;
+  // a step runs beside the capped encoder while blocks are still being fed, and for one more step after the last feed
+  // (the blocks queued during a step run at about half speed: through the step that follows)
+  int corun_tail = 1;
+  auto corun_step = [&]() {
+    if (!fed) return false;
+    if (!sam_enq_done_) return true;
+    return corun_tail-- > 0;
+  };
   for (int step = 0; step < max_new_tokens; ++step) {
     int64_t* tok = next_host_ + (size_t)(step & 1) * c.max_batch;
     const bool last = step == max_new_tokens - 1;
     HIP_TRY(hipMemcpyAsync(tok, next_dev_, B * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipEventRecord(ev_tok_[step & 1], s));
     if (ahead && !last) {
-      decode_step_graph(s, B, keep_q);
+      decode_step_graph(s, B, keep_q, corun_step());
       if (fed) sam_feed(sam_next_blk_ + per_step, true);  // the encoder's share of this step (host is idle until the token)
     }
     HIP_TRY(hipEventSynchronize(ev_tok_[step & 1]));
@@ -1883,7 +1904,7 @@ void Model<T, TS>::generate(hipStream_t s, const float* clip_images, const float
     }
     if (all || last) break;
     if (!ahead) {
-      decode_step_graph(s, B, keep_q);
+      decode_step_graph(s, B, keep_q, corun_step());
       if (fed) sam_feed(sam_next_blk_ + per_step, true);
     }
   }
