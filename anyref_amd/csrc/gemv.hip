@@ -151,27 +151,32 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int b0, int nb) {
       }
     }
     if (items > 0) load_item(0, wcur);
+    // sums of squares of ALL batch rows behind ONE barrier (a barrier per row: NB dependent LDS round trips per launch)
+    float scale[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      float ss = 0.f;
+#pragma unroll
+      for (int i = 0; i < XPT; ++i) ss += xr[b][i] * xr[b][i];
+      ss = wave_sum(ss);
+      if (lane == 0) red[b][wave] = ss;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      float tot = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) tot += red[b][w];
+      scale[b] = rsqrtf(tot / (float)K + a.eps);
+    }
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       if (b >= nb) continue;
-      float scale = 1.f;
-      if (a.gain) {
-        float ss = 0.f;
-#pragma unroll
-        for (int i = 0; i < XPT; ++i) ss += xr[b][i] * xr[b][i];
-        ss = wave_sum(ss);
-        if (lane == 0) red[b][wave] = ss;
-        __syncthreads();
-        float tot = 0.f;
-#pragma unroll
-        for (int w = 0; w < 8; ++w) tot += red[b][w];
-        scale = rsqrtf(tot / (float)K + a.eps);
-      }
 #pragma unroll
       for (int i = 0; i < XPT; ++i) {
         const int k = tid + i * 512;
         if (k < K) {
-          const float v = xr[b][i] * scale * gr[i];
+          const float v = xr[b][i] * scale[b] * gr[i];
           xs[b * K + k] = from_f32<T>(v);
           // the normalised row itself is an output of the step (last-layer hidden state before lm_head)
           if (a.xn_out && blockIdx.x == 0)
@@ -266,29 +271,34 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int b0, int nb) {
             for (int b = 0; b < NB; ++b) acc[r][b] += red2[buf][wave >> 1][r][b];
         }
       }
-      if (lane == 0 && half == 0) {
+      // Every lane holds every reduced sum (xor butterfly): lane i < R * NB finishes output (r, b) = (i / NB, i % NB) --
+      // scale / bias / activation / residual load / store side by side.  One lane walking the R * NB outputs is a chain of
+      // dependent residual load -> store round trips (y may alias the residual, so the compiler keeps their order): 8 per
+      // row group at 4 batch rows, on the wave's critical path at the end of the launch.
+      if (lane < R * NB && half == 0) {
+        const int r = lane / NB, b = lane % NB, n = n0 + r;
+        float v = 0.f, v2 = 0.f;
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-          const int n = n0 + r;
-          if (n >= a.N) continue;
+        for (int rr = 0; rr < R; ++rr)
 #pragma unroll
-          for (int b = 0; b < NB; ++b) {
-            if (b >= nb) continue;
-            float v = acc[r][b];
-            float v2 = DUAL ? acc[RW - 1][b] : 0.f;
-            if constexpr (W8) {
-              v *= a.wscale[(int64_t)n * a.ws_stride];
-              if (DUAL) v2 *= a.wscale2[(int64_t)n * a.ws_stride];
+          for (int bb = 0; bb < NB; ++bb)
+            if (lane == rr * NB + bb) {
+              v = acc[rr][bb];
+              v2 = DUAL ? acc[RW - 1][bb] : 0.f;
             }
-            if (a.bias) v += a.bias[n];
-            if (DUAL)
-              v = apply_act(v, ACT_SILU) * v2;
-            else
-              v = apply_act(v, a.act);
-            const int64_t o = (int64_t)(b0 + b) * a.ldy + n;
-            if (a.resid) v += a.resid[o];
-            a.y[o] = v;
+        if (n < a.N && b < nb) {
+          if constexpr (W8) {
+            v *= a.wscale[(int64_t)n * a.ws_stride];
+            if (DUAL) v2 *= a.wscale2[(int64_t)n * a.ws_stride];
           }
+          if (a.bias) v += a.bias[n];
+          if (DUAL)
+            v = apply_act(v, ACT_SILU) * v2;
+          else
+            v = apply_act(v, a.act);
+          const int64_t o = (int64_t)(b0 + b) * a.ldy + n;
+          if (a.resid) v += a.resid[o];
+          a.y[o] = v;
         }
       }
 #pragma unroll
