@@ -135,19 +135,22 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int b0, int nb) {
       }
     }
   } else {
-    float xr[NB][XPT], gr[XPT];
+    // RMSNorm path: x and the gain as 16-byte loads (XV per thread and row; launch_gemv checks the alignment) -- dword
+    // loads were XPT per row: 40 load instructions per thread at 4 batch rows in front of the first weight load
+    constexpr int XV = (XPT + 3) / 4;  // float4 per thread
+    float4v xr[NB][XV], gr[XV];
 #pragma unroll
-    for (int i = 0; i < XPT; ++i) {  // RMSNorm gain rides in the same round trip as x
-      const int k = tid + i * 512;
-      gr[i] = (a.gain && k < K) ? a.gain[k] : 1.f;
+    for (int i = 0; i < XV; ++i) {
+      const int k = (tid + i * 512) * 4;
+      gr[i] = k < K ? *reinterpret_cast<const float4v*>(a.gain + k) : float4v{1.f, 1.f, 1.f, 1.f};
     }
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       const float* x = a.x + (int64_t)(b0 + (b < nb ? b : 0)) * a.ldx;
 #pragma unroll
-      for (int i = 0; i < XPT; ++i) {
-        const int k = tid + i * 512;
-        xr[b][i] = (b < nb && k < K) ? x[k] : 0.f;
+      for (int i = 0; i < XV; ++i) {
+        const int k = (tid + i * 512) * 4;
+        xr[b][i] = (b < nb && k < K) ? *reinterpret_cast<const float4v*>(x + k) : float4v{0.f, 0.f, 0.f, 0.f};
       }
     }
     if (items > 0) load_item(0, wcur);
@@ -157,7 +160,9 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int b0, int nb) {
     for (int b = 0; b < NB; ++b) {
       float ss = 0.f;
 #pragma unroll
-      for (int i = 0; i < XPT; ++i) ss += xr[b][i] * xr[b][i];
+      for (int i = 0; i < XV; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ss += xr[b][i][e] * xr[b][i][e];
       ss = wave_sum(ss);
       if (lane == 0) red[b][wave] = ss;
     }
@@ -173,14 +178,14 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int b0, int nb) {
     for (int b = 0; b < NB; ++b) {
       if (b >= nb) continue;
 #pragma unroll
-      for (int i = 0; i < XPT; ++i) {
-        const int k = tid + i * 512;
+      for (int i = 0; i < XV; ++i) {
+        const int k = (tid + i * 512) * 4;
         if (k < K) {
-          const float v = xr[b][i] * scale[b] * gr[i];
-          xs[b * K + k] = from_f32<T>(v);
+          const float4v v = xr[b][i] * scale[b] * gr[i];
+          store4_from_f32<T>(&xs[b * K + k], v[0], v[1], v[2], v[3]);
           // the normalised row itself is an output of the step (last-layer hidden state before lm_head)
           if (a.xn_out && blockIdx.x == 0)
-            a.xn_out[(int64_t)(a.xn_row_map ? a.xn_row_map[b0 + b] : b0 + b) * a.xn_ld + k] = v;
+            *reinterpret_cast<float4v*>(a.xn_out + (int64_t)(a.xn_row_map ? a.xn_row_map[b0 + b] : b0 + b) * a.xn_ld + k) = v;
         }
       }
     }
@@ -397,8 +402,9 @@ void launch_gemv(const GemvArgs& a, hipStream_t s) {
   if (a.K % VN || ((uintptr_t)a.W & 15)) throw std::runtime_error("gemv: K must be a multiple of 16 bytes");
   if (a.w_fp8 && (sizeof(T) != 2 || !a.wscale || (a.W2 && !a.wscale2)))
     throw std::runtime_error("gemv: fp8 weights need the bf16 mode and per-row scales");
-  if (!a.gain && (((uintptr_t)a.x & 15) || a.ldx % 4 || a.K % 4))
-    throw std::runtime_error("gemv: x rows must be 16-byte aligned");
+  if (((uintptr_t)a.x & 15) || a.ldx % 4 || a.K % 4 || (a.gain && ((uintptr_t)a.gain & 15)) ||
+      (a.xn_out && (((uintptr_t)a.xn_out & 15) || a.xn_ld % 4)))
+    throw std::runtime_error("gemv: x / gain / xn_out rows must be 16-byte aligned");
   constexpr int NBMAX = sizeof(T) == 2 ? 4 : 2;
   for (int b0 = 0; b0 < a.B; b0 += NBMAX) {
     const int nb = a.B - b0 < NBMAX ? a.B - b0 : NBMAX;
