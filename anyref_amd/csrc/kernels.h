@@ -210,6 +210,14 @@ struct NormArgs {
   int rms = 0;
   int y_f32 = 0;
   int act = ACT_NONE;  // applied after the affine (LayerNorm2d -> GELU in the upscaler)
+  // optional side job of the wide-row kernel (SAM window layers: the q/k/v rows of a window's zero-padded tokens are
+  // exactly the qkv bias, image_encoder.py:175-179): fill_n extra workgroups write fill_dst[fill_rows[i], 0:fill_N) =
+  // T(fill_bias) -- one launch less per layer (6.4 us each).  Honoured by norm_wide_kernel only (*fill_done says so).
+  void* fill_dst = nullptr;
+  int fill_ld = 0, fill_n = 0, fill_N = 0;
+  const int* fill_rows = nullptr;
+  const float* fill_bias = nullptr;
+  bool* fill_done = nullptr;
 };
 template <typename T>
 void launch_norm(const NormArgs& a, hipStream_t s);

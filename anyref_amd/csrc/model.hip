@@ -1421,9 +1421,17 @@ void Model<T, TS>::sam_encoder(hipStream_t s, const float* images, int B, float*
       // qkv over the REAL tokens only, scattered into the window layout by the GEMM epilogue; the pad rows of
       // a window (zero input after norm1, image_encoder.py:175-179) get exactly the bias.  16 % fewer GEMM
       // rows at SAM-H (4900 -> 4096 per image), which also makes the 256^2 tile fit (240 tiles).
-      norm<TS>(s, s_x_, D, L.ln1, s_hglob_, D, RT, D, 1e-6f, false);
+      bool filled = false;
+      {  // norm1, with the pad rows of the window layout (q/k/v = the bias) written by extra workgroups of the same launch
+        NormArgs na;
+        na.x = s_x_; na.ldx = D; na.gain = L.ln1.g; na.bias = L.ln1.b; na.y = s_hglob_; na.ldy = D; na.M = RT; na.D = D;
+        na.eps = 1e-6f;
+        na.fill_dst = s_qkv_; na.fill_ld = 3 * D; na.fill_rows = pad_rows_; na.fill_n = n_pad_rows_ * B; na.fill_bias = L.qkv.b;
+        na.fill_N = 3 * D; na.fill_done = &filled;
+        launch_norm<TS>(na, s);
+      }
       gemm(s, s_hglob_, D, L.qkv, s_qkv_, 3 * D, RT, ACT_NONE, false, nullptr, 0, tok2win_);
-      launch_fill_rows_bias<TS>(s_qkv_, 3 * D, pad_rows_, n_pad_rows_ * B, L.qkv.b, 3 * D, s);
+      if (!filled) launch_fill_rows_bias<TS>(s_qkv_, 3 * D, pad_rows_, n_pad_rows_ * B, L.qkv.b, 3 * D, s);
       if (attention_takes_rel_tables((int)sizeof(TS), hd, S2, S2, ws, ws)) {
         // window bias straight from the tables inside the attention kernel (rows 0.. = rel_pos_h, Np.. = rel_pos_w)
         a.rel_tab_h = L.rel.w; a.rel_tab_w = L.rel.w + (size_t)(L.rel.n / 2) * L.rel.k; a.rel_tab_ld = L.rel.k;

@@ -274,6 +274,14 @@ __global__ __launch_bounds__(256) void norm_kernel(NormArgs a) {
 // stays in registers between the statistics and the normalise pass.
 template <typename T, int NV>  // NV float4 per thread: D <= 256*4*NV
 __global__ __launch_bounds__(256) void norm_wide_kernel(NormArgs a) {
+  if ((int)blockIdx.x >= a.M) {  // the side job: one bias row per extra workgroup (fill_N % 4 == 0, 8-byte aligned rows)
+    T* d = reinterpret_cast<T*>(a.fill_dst) + (int64_t)a.fill_rows[blockIdx.x - a.M] * a.fill_ld;
+    for (int n = threadIdx.x * 4; n < a.fill_N; n += 256 * 4) {
+      const float4v b = *reinterpret_cast<const float4v*>(a.fill_bias + n);
+      store4_from_f32<T>(d + n, b[0], b[1], b[2], b[3]);
+    }
+    return;
+  }
   const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int dm = a.row_map ? a.row_map[m] : m;
   if (dm < 0) return;
@@ -344,7 +352,14 @@ void launch_norm(const NormArgs& a, hipStream_t s) {
   if (a.M <= 0) return;
   if (a.D >= 1024 && a.D % 4 == 0 && a.ldx % 4 == 0 && a.ldy % 4 == 0 && !((uintptr_t)a.x & 15) &&
       !((uintptr_t)a.y & 15) && !((uintptr_t)a.gain & 15) && !((uintptr_t)a.bias & 15) && a.D <= 8192) {
-    dim3 g(a.M), b(256);
+    int extra = 0;
+    if (a.fill_done) *a.fill_done = false;
+    if (a.fill_n > 0 && a.fill_dst && a.fill_bias && a.fill_N % 4 == 0 && a.fill_ld % 4 == 0 && !((uintptr_t)a.fill_dst & 15) &&
+        !((uintptr_t)a.fill_bias & 15)) {
+      extra = a.fill_n;
+      if (a.fill_done) *a.fill_done = true;
+    }
+    dim3 g(a.M + extra), b(256);
     if (a.D <= 2048)
       hipLaunchKernelGGL((norm_wide_kernel<T, 2>), g, b, 0, s, a);
     else if (a.D <= 4096)
