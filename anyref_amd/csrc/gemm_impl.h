@@ -494,6 +494,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs a) {
     const int row = (r * NW + wave) * 8 + srow;
     int gm = m0 + row;
     gm = gm < a.M ? gm : a.M - 1;
+    if (a.a_row_map) gm = a.a_row_map[gm];
     asrc[r] = A + (int64_t)gm * a.lda + ((sp ^ ((row >> 1) & 7)) << 3);
   }
 #pragma unroll
@@ -892,6 +893,8 @@ void launch_gemm(const GemmArgs& a_in, hipStream_t s) {
   }
   constexpr int BK = sizeof(T) == 2 ? 64 : 16;
   if (a.M <= 0 || a.N <= 0) return;
+  if (a.a_row_map && (sizeof(T) != 2 || a.K % 64 || knobs().no_glds || knobs().tile >= 0 || a.batch != 1))
+    throw std::runtime_error("gemm: a_row_map is taken by the 16-bit LDS-DMA kernel only (K % 64 == 0, batch 1)");
   if (a.K % VEC || a.lda % VEC || a.ldw % VEC || ((uintptr_t)a.A & 15) || ((uintptr_t)a.W & 15) ||
       (a.sA % VEC) || (a.sW % VEC))
     throw std::runtime_error("gemm: K/lda/ldw must be multiples of 16 bytes and operands 16-byte aligned");
@@ -990,7 +993,8 @@ void launch_gemm(const GemmArgs& a_in, hipStream_t s) {
               for (int m0 = 0; m0 < a.M; m0 += rows) {
                 GemmArgs c = a;
                 c.M = std::min(rows, a.M - m0);
-                c.A = reinterpret_cast<const T*>(a.A) + (int64_t)m0 * a.lda;
+                if (a.a_row_map) c.a_row_map = a.a_row_map + m0;  // (logical rows m0 ..: A itself stays)
+                else c.A = reinterpret_cast<const T*>(a.A) + (int64_t)m0 * a.lda;
                 if (a.row_map) {
                   c.row_map = a.row_map + m0;  // C / resid are indexed by the mapped (destination) row
                 } else {

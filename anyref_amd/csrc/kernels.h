@@ -120,6 +120,9 @@ struct GemmArgs {
   void* C = nullptr;  // T or f32 [*, N], row stride ldc
   const float* resid = nullptr;  // f32, row stride ldr, indexed by destination row; may alias C
   const int* row_map = nullptr;  // destination row of source row m, or <0 to drop the row
+  // source row of A for logical row m (16-bit LDS-DMA kernel only): the SAM window layers' proj reads the attention
+  // output in window layout but multiplies the REAL tokens only, in token order (4096 of 4900 rows per image)
+  const int* a_row_map = nullptr;
   int M = 0, N = 0, K = 0;
   int lda = 0, ldw = 0, ldc = 0, ldr = 0;
   int act = ACT_NONE;

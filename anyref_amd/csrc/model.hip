@@ -206,7 +206,7 @@ class Model : public ModelBase {
   template <typename E>
   bool gemm(hipStream_t s, const E* A, int lda, const Lin<E>& l, void* C, int ldc, int M, int act, bool c_f32,
             const float* resid = nullptr, int ldr = 0, const int* row_map = nullptr, const Affine* nrm = nullptr,
-            void* nrm_out = nullptr, bool swiglu = false, float ln_eps = -1.f) {  // nrm_out: E rows
+            void* nrm_out = nullptr, bool swiglu = false, float ln_eps = -1.f, const int* a_row_map = nullptr) {  // nrm_out: E rows
     // nrm / nrm_out: the norm that follows (RMSNorm with the LLM's eps; LayerNorm with ln_eps when ln_eps >= 0) is
     // applied by the split-K reduction if the GEMM takes that path -- the return value says whether it did
     GemmArgs a;
@@ -221,6 +221,7 @@ class Model : public ModelBase {
     }
     a.A = A; a.lda = lda; a.W = l.w; a.ldw = l.stride(); a.bias = l.b; a.C = C; a.ldc = ldc; a.M = M; a.N = l.n;
     a.K = l.k; a.act = act; a.c_f32 = c_f32 ? 1 : 0; a.resid = resid; a.ldr = ldr; a.row_map = row_map;
+    a.a_row_map = a_row_map;
     a.max_wg = cap_wg_;
     if constexpr (std::is_same<E, T>::value) {
       if (l.w8) {
@@ -1441,7 +1442,12 @@ void Model<T, TS>::sam_encoder(hipStream_t s, const float* images, int B, float*
       a.q_bs = a.k_bs = a.v_bs = (int64_t)S2 * 3 * D; a.o_bs = (int64_t)S2 * D;
       a.B = B * nW; a.Sq = S2; a.Sk = S2; a.kh = ws; a.kw = ws;
       launch_attention<TS>(a, s);
-      gemm(s, s_att_, D, L.proj, s_x_, D, RW, ACT_NONE, true, s_x_, D, win2tok_);
+      // proj over the REAL tokens only, gathered from the window layout by the GEMM's A-row map (the pad rows' outputs
+      // were dropped by the epilogue before: 4900 -> 4096 rows per image, as for qkv)
+      if (sizeof(TS) == 2 && D % 64 == 0)
+        gemm(s, s_att_, D, L.proj, s_x_, D, RT, ACT_NONE, true, s_x_, D, nullptr, nullptr, nullptr, false, -1.f, tok2win_);
+      else
+        gemm(s, s_att_, D, L.proj, s_x_, D, RW, ACT_NONE, true, s_x_, D, win2tok_);
     }
     norm<TS>(s, s_x_, D, L.ln2, s_hglob_, D, RT, D, 1e-6f, false);
     gemm(s, s_hglob_, D, L.lin1, s_mlp_, c.sam_mlp_ratio * D, RT, ACT_GELU, false);
