@@ -99,6 +99,7 @@ SYMBOLS = {
     "anyref_op_norm": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _F, _I]),
     "anyref_op_attention": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P, _P, _P, _I, _I]),
     "anyref_op_attention_tab": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _I, _I, _I]),
+    "anyref_op_gemm_gather": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I]),
     "anyref_op_attention_relp": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _I, _I, _I]),
     "anyref_op_rel_pos": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "anyref_op_postprocess": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),

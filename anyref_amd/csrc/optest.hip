@@ -93,6 +93,18 @@ int anyref_op_attention_tab(int t, void* stream, const void* q, const void* k, c
   });
 }
 
+int anyref_op_gemm_gather(int t, void* stream, const void* A, const int32_t* a_row_map, const void* W, const float* bias,
+                          void* C, const float* resid, int M, int N, int K, int c_f32) {
+  OP_GUARD({
+    GemmArgs a;
+    a.A = A; a.lda = K; a.W = W; a.ldw = K; a.bias = bias; a.C = C; a.ldc = N; a.resid = resid; a.ldr = N;
+    a.a_row_map = a_row_map; a.M = M; a.N = N; a.K = K; a.c_f32 = c_f32;
+    if (t == 2) launch_gemm<f16>(a, (hipStream_t)stream);
+    else if (t == 1) launch_gemm<bf16>(a, (hipStream_t)stream);
+    else throw std::runtime_error("gemm_gather: 16-bit types only");
+  });
+}
+
 int anyref_op_attention_relp(int t, void* stream, const void* q, const void* k, const void* v, void* o, int B, int H, int S,
                              int hd, float scale, const float* rel_p, int rel_ld, int kh, int kw) {
   OP_GUARD({

@@ -90,6 +90,11 @@ int anyref_op_kaldi_fbank(void* stream, const float* wave, int C, int T, int win
  * takes (hd 80, 192 < S <= 208); others are refused. */
 int anyref_op_attention_tab(int t, void* stream, const void* q, const void* k, const void* v, void* o, int B, int H, int S,
                             int hd, float scale, const void* tab_h, const void* tab_w, int tab_ld, int kh, int kw);
+/* 16-bit GEMM with an A-row gather: C[m, :] = A[a_row_map[m], :] W^T + bias (+ resid[m, :]) -- the SAM window layers'
+ * proj over the real tokens of the window-layout attention output (model.hip sam_encoder; image_encoder.py:196-229,
+ * window_unpartition).  t = 1 (bf16) / 2 (f16); K % 64 == 0. */
+int anyref_op_gemm_gather(int t, void* stream, const void* A, const int32_t* a_row_map, const void* W, const float* bias,
+                          void* C, const float* resid, int M, int N, int K, int c_f32);
 /* the same attention with the bias taken from the P buffer the model's batched rel-pos GEMM writes (model.hip
  * sam_encoder, image_encoder.py:354-392): P f32 [H][B*S][rel_ld], columns [0, rel_ld/2) = q . rel_pos_h[e],
  * [rel_ld/2, rel_ld) = q . rel_pos_w[e]; the kernel applies the get_rel_pos shift.  S = kh*kw tokens, [B,S,H,hd]

@@ -115,6 +115,22 @@ def test_gemm_row_map_and_typed_out(lib, ty):
     close(out, ref, {0: 1e-4, 1: 1e-2, 2: 2e-3}[ty])
 
 
+@pytest.mark.parametrize("ty", [1, 2])
+@pytest.mark.parametrize("M,Msrc,N,K,c_f32", [(4096, 4900, 1280, 1280, 1), (300, 517, 200, 128, 0), (1000, 1000, 384, 256, 1)])
+def test_gemm_a_row_gather(lib, ty, M, Msrc, N, K, c_f32):
+    """C[m] = A[map[m]] W^T + bias + resid[m]: the SAM window layers' proj over the real tokens of the window layout
+    (image_encoder.py:196-229); first shape = SAM-H's (4096 tokens out of 4900 window rows, f32 output + residual)."""
+    g = torch.Generator().manual_seed(M + N + K)
+    A, W = torch.randn(Msrc, K, generator=g), torch.randn(N, K, generator=g) * 0.05
+    bias, resid = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    amap = torch.randperm(Msrc, generator=g)[:M].to(torch.int32)
+    ref = rnd(A, ty)[amap.long()] @ rnd(W, ty).t() + bias + (resid if c_f32 else 0)
+    out = torch.empty(M, N, device="cuda", dtype=torch.float32 if c_f32 else _DT[ty])
+    check(lib, lib.anyref_op_gemm_gather(ty, None, P(dev(A, ty)), P(amap.cuda()), P(dev(W, ty)), P(bias.cuda()), P(out),
+                                         P(resid.cuda()) if c_f32 else None, M, N, K, c_f32))
+    close(out, ref, {1: 1e-2, 2: 2e-3}[ty])
+
+
 @pytest.mark.parametrize("ty", [0, 1])
 @pytest.mark.parametrize("B,N,K,dual,norm", [(1, 512, 256, 0, 1), (2, 1000, 688, 1, 1), (4, 300, 1024, 0, 0),
                                              (3, 64, 4096, 1, 0), (1, 33, 11008, 0, 1),
