@@ -1055,7 +1055,10 @@ void launch_gemm(const GemmArgs& a_in, hipStream_t s) {
         go(I128(), I128(), I2(), I4(), I2(), "gemm_bf16_128x128g");
         return;
       }
-      if (a.M >= 1024 && fill256 >= 0.85) {
+      // 256^2 from 80 % fill of whole rounds of the chip (lab knob ANYREF_GEMM_FILL256; it was 0.85: prefill gate/up at four
+      // sequences -- 1280 x 22016 x 4096, 430 tiles = 0.84 -- went to 1720 tiles of 128^2: 267 us against 230 us on 256^2)
+      static const double fill256_min = getenv("ANYREF_GEMM_FILL256") ? atof(getenv("ANYREF_GEMM_FILL256")) : 0.80;
+      if (a.M >= 1024 && fill256 >= fill256_min) {
         go(I256(), I256(), I2(), I4(), I2(), "gemm_bf16_256x256");
         return;
       }
