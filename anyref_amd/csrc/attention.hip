@@ -1061,7 +1061,7 @@ static void attn_launch(const AttnArgs& a, hipStream_t s) {
     }
     // SAM global attention with the bias in the P buffer and one 64-key tile per grid row: two query blocks per wave
     if (a.Sq >= 1024 && !a.causal && a.rel_p && a.kw == 64 && a.kh * a.kw == a.Sk && a.Sq == a.Sk && !a.kv_len && !a.q_len &&
-        !a.q_pos0 && a.o_rs % 4 == 0 && a.o_hs % 4 == 0 && a.o_bs % 4 == 0) {
+        !a.q_pos0 && a.o_rs % 4 == 0 && a.o_hs % 4 == 0 && a.o_bs % 4 == 0 && !((uintptr_t)a.O & 15) && a.rel_ld % 2 == 0) {
       // (lab knob: 0 = the general kernel below, 4 / 8 waves; SAM-H, 16 heads, scratch/bench_attn_global.py: 314 us general,
       // 195 us with 4 waves -- two workgroups per CU --, 186 us with 8)
       static const int g2 = getenv("ANYREF_ATTN_G2") ? atoi(getenv("ANYREF_ATTN_G2")) : 8;
