@@ -128,10 +128,7 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int b0, int nb) {
 #pragma unroll
       for (int i = 0; i < XV; ++i) {
         const int k = (tid + i * 512) * 4;
-        if (k < K) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) xs[b * K + k + e] = from_f32<T>(xv[b][i][e]);
-        }
+        if (k < K) store4_from_f32<T>(&xs[b * K + k], xv[b][i][0], xv[b][i][1], xv[b][i][2], xv[b][i][3]);  // one LDS store
       }
     }
   } else {
