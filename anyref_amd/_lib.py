@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(HERE, "libanyref_hip.so")
 
 ABI_VERSION = 2
 F32, BF16, F16 = 0, 1, 2
-MODE_PARITY, MODE_PERF, MODE_PERF_FP8W = 0, 1, 2
+MODE_PARITY, MODE_PERF, MODE_PERF_FP8W, MODE_PARITY16 = 0, 1, 2, 3
 
 
 class AnyrefConfig(C.Structure):

@@ -649,6 +649,8 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const int bx, const
         reinterpret_cast<uint16_t*>(Ob)[c + 1] = from_f32<T>(v[1]).x;
         reinterpret_cast<uint16_t*>(Ob)[c + 2] = from_f32<T>(v[2]).x;
         reinterpret_cast<uint16_t*>(Ob)[c + 3] = from_f32<T>(v[3]).x;
+      } else if (a.o_split) {  // split-pair rows (the proj / o_proj GEMM's A operand in ANYREF_MODE_PARITY16)
+        st4<sp16>(reinterpret_cast<sp16*>(a.O) + (int64_t)b * a.o_bs + (int64_t)iq * a.o_rs, (int)(h * a.o_hs) + c, v[0], v[1], v[2], v[3]);
       } else {
         Ob[c] = v[0]; Ob[c + 1] = v[1]; Ob[c + 2] = v[2]; Ob[c + 3] = v[3];
       }
@@ -892,6 +894,7 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(AttnArgs a, int HD) {
   const float v = l > 0.f ? o / l : 0.f;
   const int64_t off = (int64_t)b * a.o_bs + (int64_t)h * a.o_hs + (int64_t)iq * a.o_rs + d;
   if (a.o_f32) reinterpret_cast<float*>(a.O)[off] = v;
+  else if (a.o_split) st1<sp16>(reinterpret_cast<sp16*>(a.O) + (int64_t)b * a.o_bs + (int64_t)iq * a.o_rs, (int)(h * a.o_hs) + d, v);
   else reinterpret_cast<T*>(a.O)[off] = from_f32<T>(v);
 }
 
@@ -1102,6 +1105,8 @@ template <typename T>
 void launch_attention(const AttnArgs& a, hipStream_t s) {
   if (a.B <= 0 || a.Sq <= 0) return;
   constexpr int VEC = AMma<T>::VEC;
+  if (a.o_split && (sizeof(T) != 4 || a.o_f32 || a.o_rs % 64 || a.o_bs % 64 || a.o_hs % 4))
+    throw std::runtime_error("attention: a split-pair output goes with f32 operands and whole-row strides");
   if (a.q_rs % VEC || a.k_rs % VEC || a.v_rs % VEC || a.q_hs % VEC || a.k_hs % VEC || a.v_hs % VEC ||
       a.q_bs % VEC || a.k_bs % VEC || a.v_bs % VEC)
     throw std::runtime_error("attention: strides must be multiples of 16 bytes");

@@ -111,6 +111,83 @@ __device__ inline uint32_t pack2_from_f32(float lo, float hi) {
   return (uint32_t)from_f32<T>(lo).x | ((uint32_t)from_f32<T>(hi).x << 16);
 }
 
+// ---- split-pair activations (ANYREF_MODE_PARITY16) ---------------------------------------------
+// An f32 activation a is carried as TWO bf16 terms, hi = bf16(a) and lo = bf16(a - hi): |a - hi - lo| <= 2^-18 |a|
+// (bf16 alone: 2^-9).  A bf16 weight times each term is exact in the MFMA's f32 accumulator, so a GEMM over the pair
+// is the f32 product of the activation with the (exactly stored) 16-bit weight to ~4e-6 relative -- at two 16-bit MFMA
+// passes instead of the f32 MFMA's 1/16 rate, and with the weights never widened in HBM.
+// Layout of a [rows, K] sp16 matrix (K % 64 == 0, 4 bytes per element like f32): every row is K / 64 blocks of
+// [64 x hi | 64 x lo] bf16 -- exactly the 64-wide K tiles of the LDS-DMA GEMM, which walks 2K/64 tiles of A against
+// K/64 tiles of W (W tile index = A tile index >> 1): no kernel-side conversion, no second weight copy.
+struct sp16 {
+  uint32_t x;
+};
+template <typename T>
+struct is_split {
+  static constexpr bool value = false;
+};
+template <>
+struct is_split<sp16> {
+  static constexpr bool value = true;
+};
+// bf16 index (inside the row) of the hi term of logical column c; the lo term sits 64 elements further
+__host__ __device__ inline int sp_col(int c) { return ((c >> 6) << 7) + (c & 63); }
+__device__ inline void sp_split(float v, uint16_t& hi, uint16_t& lo) {
+  const bf16 h = f2bf(v);
+  hi = h.x;
+  lo = f2bf(v - bf2f(h)).x;
+}
+__device__ inline float sp_load(const sp16* row, int c) {
+  const bf16* p = reinterpret_cast<const bf16*>(row) + sp_col(c);
+  return bf2f(p[0]) + bf2f(p[64]);
+}
+
+// Typed row stores: `row` points at the first element of a matrix row, c is the logical column.
+template <typename T>
+__device__ inline void st1(T* row, int c, float v) {
+  if constexpr (is_split<T>::value) {
+    uint16_t* p = reinterpret_cast<uint16_t*>(row) + sp_col(c);
+    uint16_t h, l;
+    sp_split(v, h, l);
+    p[0] = h;
+    p[64] = l;
+  } else {
+    row[c] = from_f32<T>(v);
+  }
+}
+template <typename T>
+__device__ inline void st2(T* row, int c, float a, float b) {  // c % 2 == 0
+  if constexpr (is_split<T>::value) {
+    uint16_t* p = reinterpret_cast<uint16_t*>(row) + sp_col(c);
+    uint16_t h0, l0, h1, l1;
+    sp_split(a, h0, l0);
+    sp_split(b, h1, l1);
+    *reinterpret_cast<uint32_t*>(p) = (uint32_t)h0 | ((uint32_t)h1 << 16);
+    *reinterpret_cast<uint32_t*>(p + 64) = (uint32_t)l0 | ((uint32_t)l1 << 16);
+  } else if constexpr (sizeof(T) == 2) {
+    *reinterpret_cast<uint32_t*>(row + c) = pack2_from_f32<T>(a, b);
+  } else {
+    row[c] = from_f32<T>(a);
+    row[c + 1] = from_f32<T>(b);
+  }
+}
+template <typename T>
+__device__ inline void st4(T* row, int c, float a, float b, float cc, float d) {  // c % 4 == 0, aligned rows
+  if constexpr (is_split<T>::value) {
+    typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+    uint16_t* p = reinterpret_cast<uint16_t*>(row) + sp_col(c);
+    uint16_t h[4], l[4];
+    sp_split(a, h[0], l[0]);
+    sp_split(b, h[1], l[1]);
+    sp_split(cc, h[2], l[2]);
+    sp_split(d, h[3], l[3]);
+    *reinterpret_cast<u2*>(p) = u2{(uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16)};
+    *reinterpret_cast<u2*>(p + 64) = u2{(uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16)};
+  } else {
+    store4_from_f32<T>(row + c, a, b, cc, d);
+  }
+}
+
 // ---- vector types --------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(8))) short short8;   // 8 x bf16 = one MFMA A/B fragment
 typedef __attribute__((ext_vector_type(4))) float float4v;  // MFMA 16x16 accumulator

@@ -49,6 +49,11 @@ struct Mma<f16> {
   static __device__ inline float4v mma(Frag a, Frag b, float4v c) { return mfma_16x16x32<f16>(a, b, c); }
 };
 template <>
+struct Mma<sp16> {  // split-pair activations: the LDS-DMA kernel only (bf16 MFMA); the constants are what the launcher reads
+  static constexpr int KS = 32;
+  static constexpr int VEC = 8;
+};
+template <>
 struct Mma<float> {
   static constexpr int KS = 4;
   static constexpr int VEC = 4;
@@ -93,6 +98,8 @@ __device__ __forceinline__ void epi_store4(const GemmArgs& a, const float* bias,
       if (a.c_f32) {
         Cf[off] = o0;
         Cf[off + 1] = o1;
+      } else if constexpr (is_split<T>::value) {
+        st2<T>(Ct + (int64_t)dm * a.ldc, n >> 1, o0, o1);
       } else if constexpr (sizeof(T) == 2) {
         *reinterpret_cast<uint32_t*>(Ct + off) = pack2_from_f32<T>(o0, o1);
       } else {
@@ -102,10 +109,12 @@ __device__ __forceinline__ void epi_store4(const GemmArgs& a, const float* bias,
       return;
     }
     if (bias) v += *reinterpret_cast<const float4v*>(bias + n);
-    v = float4v{act_ct<ACT, sizeof(T) == 2>(v[0]), act_ct<ACT, sizeof(T) == 2>(v[1]), act_ct<ACT, sizeof(T) == 2>(v[2]), act_ct<ACT, sizeof(T) == 2>(v[3])};
+    v = float4v{act_ct<ACT, sizeof(T) == 2 || is_split<T>::value>(v[0]), act_ct<ACT, sizeof(T) == 2 || is_split<T>::value>(v[1]), act_ct<ACT, sizeof(T) == 2 || is_split<T>::value>(v[2]), act_ct<ACT, sizeof(T) == 2 || is_split<T>::value>(v[3])};
     if (resid) v += *reinterpret_cast<const float4v*>(resid + (int64_t)dm * a.ldr + n);
     if (a.c_f32) {
       *reinterpret_cast<float4v*>(Cf + (int64_t)dm * a.ldc + n) = v;
+    } else if constexpr (is_split<T>::value) {
+      st4<T>(Ct + (int64_t)dm * a.ldc, n, v[0], v[1], v[2], v[3]);
     } else if constexpr (sizeof(T) == 2) {
       const uint32_t lo = pack2_from_f32<T>(v[0], v[1]);
       const uint32_t hi = pack2_from_f32<T>(v[2], v[3]);
@@ -123,7 +132,7 @@ __device__ __forceinline__ void epi_store4(const GemmArgs& a, const float* bias,
           const float o = apply_act(g, ACT_SILU) * u;
           const int64_t off = (int64_t)dm * a.ldc + ((n + r) >> 1);
           if (a.c_f32) Cf[off] = o;
-          else Ct[off] = from_f32<T>(o);
+          else st1<T>(Ct + (int64_t)dm * a.ldc, (n + r) >> 1, o);
         }
       }
       return;
@@ -134,12 +143,12 @@ __device__ __forceinline__ void epi_store4(const GemmArgs& a, const float* bias,
         float x = v[r];
         if (a.col_scale) x *= a.col_scale[n + r];
         if (bias) x += bias[n + r];
-        x = act_ct<ACT, sizeof(T) == 2>(x);
+        x = act_ct<ACT, sizeof(T) == 2 || is_split<T>::value>(x);
         if (resid) x += resid[(int64_t)dm * a.ldr + n + r];
         if (a.c_f32)
           Cf[(int64_t)dm * a.ldc + n + r] = x;
         else
-          Ct[(int64_t)dm * a.ldc + n + r] = from_f32<T>(x);
+          st1<T>(Ct + (int64_t)dm * a.ldc, n + r, x);
       }
     }
   }
@@ -215,8 +224,8 @@ __device__ __forceinline__ void gemm_epilogue_ct(const GemmArgs& a, float4v (&ac
           float4v v;
           if constexpr (LEAN) v = acc[i][j] * a.alpha + bv[j];
           else v = acc[i][j] * sv[j] + bv[j];
-          v = float4v{act_ct<ACT, sizeof(T) == 2>(v[0]), act_ct<ACT, sizeof(T) == 2>(v[1]), act_ct<ACT, sizeof(T) == 2>(v[2]),
-                      act_ct<ACT, sizeof(T) == 2>(v[3])};
+          v = float4v{act_ct<ACT, sizeof(T) == 2 || is_split<T>::value>(v[0]), act_ct<ACT, sizeof(T) == 2 || is_split<T>::value>(v[1]), act_ct<ACT, sizeof(T) == 2 || is_split<T>::value>(v[2]),
+                      act_ct<ACT, sizeof(T) == 2 || is_split<T>::value>(v[3])};
           vv[j] = v + rv[cur][j];
         }
 #pragma unroll
@@ -225,6 +234,27 @@ __device__ __forceinline__ void gemm_epilogue_ct(const GemmArgs& a, float4v (&ac
             const int64_t off = (int64_t)dms[i] * a.ldc + ns[j];
             if (a.c_f32) {
               *reinterpret_cast<float4v*>(Cf + off) = vv[j];
+            } else if constexpr (is_split<T>::value) {
+              // both terms of the pair as 8-byte stores (16-byte for a fragment pair: 8 consecutive columns, one 64-block)
+              uint16_t* p = reinterpret_cast<uint16_t*>(Ct + (int64_t)dms[i] * a.ldc) + sp_col(ns[j]);
+              if constexpr (PAIRED) {
+                if (j < (NI & ~1) && pair16) {
+                  if ((j & 1) == 0) {
+                    uint16_t h[8], l[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                      sp_split(vv[j][e], h[e], l[e]);
+                      sp_split(vv[j | 1][e], h[4 + e], l[4 + e]);
+                    }
+                    *reinterpret_cast<uint4v*>(p) = uint4v{(uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16),
+                                                           (uint32_t)h[4] | ((uint32_t)h[5] << 16), (uint32_t)h[6] | ((uint32_t)h[7] << 16)};
+                    *reinterpret_cast<uint4v*>(p + 64) = uint4v{(uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16),
+                                                                (uint32_t)l[4] | ((uint32_t)l[5] << 16), (uint32_t)l[6] | ((uint32_t)l[7] << 16)};
+                  }
+                  continue;
+                }
+              }
+              st4<T>(Ct + (int64_t)dms[i] * a.ldc, ns[j], vv[j][0], vv[j][1], vv[j][2], vv[j][3]);
             } else if constexpr (sizeof(T) == 2) {
               if constexpr (PAIRED) {
                 if (j < (NI & ~1) && pair16) {  // (N % 8 == 0: the pair is in range together)
@@ -416,7 +446,13 @@ __device__ __forceinline__ short8 fp8x8_to_bf16x8(uint2v r) {
 template <int BM, int BN, int WM, int WN, int NS, bool W8 = false, bool PERSIST = false, typename TT = bf16>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs a) {
   using T = TT;  // bf16 or f16 (same tile, DMA and fragment code; the MFMA and the epilogue rounding differ)
-  static_assert(!W8 || !is_half16<T>::value, "fp8 weights are widened to bf16");
+  // sp16 (split-pair activations, common.h): the A rows are 2K/64 bf16 tiles [hi | lo] per 64 logical columns, walked
+  // against K/64 tiles of the bf16 weight (W tile = A tile >> 1, re-fetched from L2 for the lo pass); the epilogue
+  // writes f32 or a split pair again.  ET: element type of both operand tiles and of the MFMA.
+  constexpr bool SPLIT = is_split<TT>::value;
+  using ET = std::conditional_t<SPLIT, bf16, TT>;
+  constexpr int AX = SPLIT ? 2 : 1;  // 16-bit elements per logical A element
+  static_assert(!W8 || !(is_half16<T>::value || SPLIT), "fp8 weights are widened to bf16");
   constexpr int BK = 64, NW = WM * WN;
   constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 16, NI = TN / 16;
   constexpr int ROWB = BK * 2;             // bytes per A tile row
@@ -475,8 +511,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs a) {
   }
   const int m0 = tm * BM, n0 = tn * BN;
   const int z = blockIdx.z;
-  const T* __restrict__ A = reinterpret_cast<const T*>(a.A) + (int64_t)z * a.sA;
-  using WT = std::conditional_t<W8, uint8_t, T>;
+  const ET* __restrict__ A = reinterpret_cast<const ET*>(a.A) + (int64_t)z * a.sA * AX;
+  using WT = std::conditional_t<W8, uint8_t, ET>;
   const WT* __restrict__ W = reinterpret_cast<const WT*>(a.W) + (int64_t)z * a.sW;
 
   float4v acc[MI][NI];
@@ -487,7 +523,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs a) {
 
   // rows past M / N fetch the last valid row (never stored); K is a multiple of 64 (launcher)
   const int srow = lane >> 3, sp = lane & 7;
-  const T* asrc[RA];
+  const ET* asrc[RA];
   const WT* wsrc[RW];
 #pragma unroll
   for (int r = 0; r < RA; ++r) {
@@ -495,7 +531,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs a) {
     int gm = m0 + row;
     gm = gm < a.M ? gm : a.M - 1;
     if (a.a_row_map) gm = a.a_row_map[gm];
-    asrc[r] = A + (int64_t)gm * a.lda + ((sp ^ ((row >> 1) & 7)) << 3);
+    asrc[r] = A + (int64_t)gm * a.lda * AX + ((sp ^ ((row >> 1) & 7)) << 3);
   }
 #pragma unroll
   for (int r = 0; r < RW; ++r) {
@@ -524,7 +560,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs a) {
 #pragma unroll
     for (int r = 0; r < RW; ++r)
       if (r < RWF || wave < PW)  // (wave-uniform)
-        __builtin_amdgcn_global_load_lds((gas_ptr)(wsrc[r] + t * BK),
+        __builtin_amdgcn_global_load_lds((gas_ptr)(wsrc[r] + (SPLIT ? t >> 1 : t) * BK),
                                          (las_ptr)(base + BM * ROWB + (r * NW + wave) * WRPI * WROWB), 16, 0, 0);
   };
   // wait until at most N tiles' worth of this wave's own DMAs are still in flight
@@ -586,7 +622,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs a) {
 #pragma unroll
           for (int h = 0; h < NH; ++h)
             acc[i * MH + f][j * NH0 + h] =
-                mfma_16x16x32<T>(bf[ks][h], af[ks][f], acc[i * MH + f][j * NH0 + h]);  // C^T tile
+                mfma_16x16x32<ET>(bf[ks][h], af[ks][f], acc[i * MH + f][j * NH0 + h]);  // C^T tile
       __builtin_amdgcn_s_setprio(0);
     };
     using I0 = std::integral_constant<int, 0>;
@@ -633,10 +669,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs a) {
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j)
-          acc[i][j] = mfma_16x16x32<T>(bfr[j], af[i], acc[i][j]);  // C^T tile
+          acc[i][j] = mfma_16x16x32<ET>(bfr[j], af[i], acc[i][j]);  // C^T tile
     }
   };
-  const int nt = a.K / BK;
+  const int nt = a.K / BK * AX;
   static_for(std::make_integer_sequence<int, NS - 1>{}, [&](auto b) {  // prologue: tiles 0 .. NS-2
     if (decltype(b)::value < nt) stage(b, decltype(b)::value);
   });
@@ -685,6 +721,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, int splits
       const float o0 = apply_act(acc[0], ACT_SILU) * acc[1], o1 = apply_act(acc[2], ACT_SILU) * acc[3];
       const int64_t off = (int64_t)m * a.ldc + (n >> 1);
       if (a.c_f32) { Cf[off] = o0; Cf[off + 1] = o1; }
+      else if constexpr (is_split<T>::value) st2<T>(Ct + (int64_t)m * a.ldc, n >> 1, o0, o1);
       else { Ct[off] = from_f32<T>(o0); Ct[off + 1] = from_f32<T>(o1); }
       continue;
     }
@@ -693,6 +730,8 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, int splits
     if (a.resid) acc += *reinterpret_cast<const float4v*>(a.resid + (int64_t)m * a.ldr + n);
     if (a.c_f32) {
       *reinterpret_cast<float4v*>(Cf + (int64_t)m * a.ldc + n) = acc;
+    } else if constexpr (is_split<T>::value) {
+      st4<T>(Ct + (int64_t)m * a.ldc, n, acc[0], acc[1], acc[2], acc[3]);
     } else {
       T* o = Ct + (int64_t)m * a.ldc + n;
       o[0] = from_f32<T>(acc[0]); o[1] = from_f32<T>(acc[1]); o[2] = from_f32<T>(acc[2]); o[3] = from_f32<T>(acc[3]);
@@ -741,6 +780,8 @@ __global__ __launch_bounds__(NT) void splitk_reduce_norm_kernel(const float* __r
       if (a.resid) acc += *reinterpret_cast<const float4v*>(a.resid + (int64_t)m * a.ldr + n);
       if (a.c_f32) {
         *reinterpret_cast<float4v*>(Cf + (int64_t)m * a.ldc + n) = acc;
+      } else if constexpr (is_split<T>::value) {
+        st4<T>(Ct + (int64_t)m * a.ldc, n, acc[0], acc[1], acc[2], acc[3]);
       } else {
         T* o = Ct + (int64_t)m * a.ldc + n;
         o[0] = from_f32<T>(acc[0]); o[1] = from_f32<T>(acc[1]); o[2] = from_f32<T>(acc[2]); o[3] = from_f32<T>(acc[3]);
@@ -790,7 +831,7 @@ __global__ __launch_bounds__(NT) void splitk_reduce_norm_kernel(const float* __r
       const float4v g = *reinterpret_cast<const float4v*>(a.norm_gain + n);
       float4v o = v[i] * scale * g;
       if (a.norm_bias) o += *reinterpret_cast<const float4v*>(a.norm_bias + n);
-      store4_from_f32<T>(y + n, o[0], o[1], o[2], o[3]);
+      st4<T>(y, n, o[0], o[1], o[2], o[3]);
     }
   }
 }
@@ -825,8 +866,15 @@ void launch_gemm(const GemmArgs& a_in, hipStream_t s) {
   if (a.swiglu_pairs && (a.N % 4 || a.bias || a.resid || a.row_map || a.act != ACT_NONE || a.batch != 1))
     throw std::runtime_error("gemm: the SwiGLU epilogue takes interleaved gate/up rows, N % 4 == 0, and nothing else");
   constexpr int VEC = Mma<T>::VEC;
+  constexpr bool SP = is_split<T>::value;         // split-pair A (and C unless c_f32), bf16 W
+  constexpr bool IS16 = sizeof(T) == 2 || SP;     // the 16-bit MFMA paths
+  if constexpr (SP) {
+    if (a.K % 64 || a.lda % 64 || a.sA % 64 || a.w_fp8 || (!a.c_f32 && !a.slabs_out && (a.ldc % 64 || a.sC % 64)) ||
+        (a.norm_out && a.norm_ld % 64))
+      throw std::runtime_error("gemm<sp16>: K, lda, the A batch stride (and ldc of a split-pair output) must be multiples of 64");
+  }
   if (a.slabs_out && a.slabs > 1) {  // raw split-K: the consumer sums the slices
-    if (sizeof(T) != 2 || a.batch != 1 || a.row_map || a.bias || a.resid || a.act != ACT_NONE || a.swiglu_pairs || a.w_fp8 ||
+    if (!IS16 || a.batch != 1 || a.row_map || a.bias || a.resid || a.act != ACT_NONE || a.swiglu_pairs || a.w_fp8 ||
         a.K % (64 * a.slabs))
       throw std::runtime_error("gemm: raw split-K slabs take a plain bf16 product with K % (64 * slabs) == 0");
     GemmArgs g = a;
@@ -841,7 +889,7 @@ void launch_gemm(const GemmArgs& a_in, hipStream_t s) {
   }
   // ---- split-K decision: few 64x64 tiles, deep K, plain row-major output ----
   // (K >= 1024 when a norm rides on the reduction: CLIP out_proj, 24 tiles of 16 K steps + a LayerNorm launch otherwise)
-  if (!knobs().no_splitk && sizeof(T) == 2 && a.batch == 1 && !a.row_map && a.M <= 512 &&
+  if (!knobs().no_splitk && IS16 && a.batch == 1 && !a.row_map && a.M <= 512 &&
       (a.K >= 2048 || (a.K >= 1024 && a.norm_out && a.norm_bias)) && a.N % 4 == 0 && a.ldc % 4 == 0 &&
       (!a.resid || a.ldr % 4 == 0)) {
     // 128 x 128 workgroups (two per CU): split until there are ~256 of them, slices of >= 512, multiples of 64
@@ -893,7 +941,7 @@ void launch_gemm(const GemmArgs& a_in, hipStream_t s) {
   }
   constexpr int BK = sizeof(T) == 2 ? 64 : 16;
   if (a.M <= 0 || a.N <= 0) return;
-  if (a.a_row_map && (sizeof(T) != 2 || a.K % 64 || knobs().no_glds || knobs().tile >= 0 || a.batch != 1))
+  if (a.a_row_map && (!IS16 || a.K % 64 || knobs().no_glds || knobs().tile >= 0 || a.batch != 1))
     throw std::runtime_error("gemm: a_row_map is taken by the 16-bit LDS-DMA kernel only (K % 64 == 0, batch 1)");
   if (a.K % VEC || a.lda % VEC || a.ldw % VEC || ((uintptr_t)a.A & 15) || ((uintptr_t)a.W & 15) ||
       (a.sA % VEC) || (a.sW % VEC))
@@ -935,8 +983,8 @@ void launch_gemm(const GemmArgs& a_in, hipStream_t s) {
                        (double)a.M * a.N * (a.c_f32 ? 4 : sizeof(T)) * a.batch;
   if (a.w_fp8 && (sizeof(T) != 2 || a.K % 64 || knobs().no_glds || knobs().tile >= 0))
     throw std::runtime_error("gemm: an fp8 weight operand needs the bf16 LDS-DMA kernel (K % 64 == 0)");
-  if constexpr (sizeof(T) == 2) {
-    if (!knobs().no_glds && a.K % 64 == 0 && knobs().tile < 0) {
+  if constexpr (IS16) {
+    if (SP || (!knobs().no_glds && a.K % 64 == 0 && knobs().tile < 0)) {
       // Tile choice from scratch/lab/gemm_lab.hip on MI355X: 256^2 when its tiles fill whole rounds of the
       // 256 CUs (SAM qkv: 240 tiles, square 8192^3), 64 x 256 for skinny-M / very wide N (prefill gate/up),
       // otherwise 128^2 with 8 waves (two workgroups per CU).
@@ -944,7 +992,7 @@ void launch_gemm(const GemmArgs& a_in, hipStream_t s) {
         constexpr int BM = decltype(bm_t)::value, BN = decltype(bn_t)::value, WM = decltype(wm_t)::value,
                       WN = decltype(wn_t)::value, NS = decltype(ns_t)::value;
         constexpr size_t lds = NS * (size_t)(BM + BN) * 128;
-        if constexpr (BN % (WM * WN * 16) == 0 && !is_half16<T>::value) {
+        if constexpr (BN % (WM * WN * 16) == 0 && !is_half16<T>::value && !SP) {
           if (a.w_fp8) {  // fp8 weight operand (LDS of the full-width kernel is an upper bound)
             auto kern8 = &gemm_glds_kernel<BM, BN, WM, WN, NS, true>;
             static bool attr8 = false;
@@ -978,8 +1026,8 @@ void launch_gemm(const GemmArgs& a_in, hipStream_t s) {
           a.group_m = knobs().gm >= 0 ? knobs().gm : gm;
         }
         char tagt[48];
-        snprintf(tagt, sizeof(tagt), "gemm_f16_%s", tag + 10);  // gemm_bf16_... -> gemm_f16_...
-        ProfScope prof(is_half16<T>::value ? tagt : tag, flops, bytes, s);
+        snprintf(tagt, sizeof(tagt), SP ? "gemm_sp16_%s" : "gemm_f16_%s", tag + 10);  // gemm_bf16_... -> gemm_f16_... / gemm_sp16_...
+        ProfScope prof(is_half16<T>::value || SP ? tagt : tag, flops, bytes, s);
         dim3 grid(cdiv(a.N, BN) * cdiv(a.M, BM), 1, a.batch);
         if constexpr (BM <= 256 && BM >= 128) {  // the SAM encoder's tiles
           // (tiles small enough for two workgroups per CU -- 128 x 128 on two stages: 64 KB -- take twice the cap: the
@@ -1106,6 +1154,9 @@ void launch_gemm(const GemmArgs& a_in, hipStream_t s) {
       return;
     }
   }
+  if constexpr (SP) {
+    throw std::runtime_error("gemm<sp16>: no register-staged fallback (unreachable)");
+  } else {
   const char* tag = is_half16<T>::value ? (bm128 ? (bn == 128 ? "gemm_f16_128x128" : "gemm_f16_128x64")
                                                  : (bn == 128 ? "gemm_f16_64x128" : "gemm_f16_64x64"))
                     : sizeof(T) == 2 ? (bm128 ? (bn == 128 ? "gemm_bf16_128x128" : "gemm_bf16_128x64")
@@ -1125,6 +1176,7 @@ void launch_gemm(const GemmArgs& a_in, hipStream_t s) {
   } else {
     dim3 grid(cdiv(a.N, 64) * cdiv(a.M, 64), 1, a.batch);
     hipLaunchKernelGGL((gemm_kernel<T, 64, 64, BK>), grid, block, 0, s, a);
+  }
   }
 }
 

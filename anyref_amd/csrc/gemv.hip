@@ -40,18 +40,23 @@ constexpr bool NO_DOT2 = ANYREF_GEMV_NO_DOT2;
 template <typename T, int NB, bool DUAL, int XPT, bool W8 = false, bool PAIR = false>  // XPT: x elements per thread in registers, K <= 512 * XPT
 __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int b0, int nb) {
   static_assert(!W8 || sizeof(T) == 2, "fp8 weights go with bf16 activations");
-  using WT = std::conditional_t<W8, uint8_t, T>;
-  constexpr int VN = W8 ? 16 : Vec16<T>::N;  // weights per 16-byte load
+  // T = sp16 (ANYREF_MODE_PARITY16): bf16 weights, exactly as stored, against the f32 activation row kept in LDS as f32
+  // (16 - 44 KB) -- same bytes per decode step as the bf16 mode, f32 products and sums
+  using WE = std::conditional_t<is_split<T>::value, bf16, T>;   // weight element
+  using XE = std::conditional_t<is_split<T>::value, float, T>;  // staged activation element
+  using WT = std::conditional_t<W8, uint8_t, WE>;
+  constexpr int VN = W8 ? 16 : Vec16<WE>::N;  // weights per 16-byte load
   constexpr int R = DUAL ? 1 : 2;   // output rows per wave per pass
   constexpr int RW = 2;             // weight rows streamed per pass (DUAL: gate row + up row)
   // 16-byte loads per row in flight per lane.  8 measured slower; 2 (68 instead of 100 VGPRs, so that a GEMV
   // workgroup fits beside a resident 256^2 GEMM workgroup of the co-running SAM stream) measured equal within
   // noise, alone and under the overlap
   constexpr int UNR = 4;
-  // packed bf16 dot products for 2 .. 4 batch rows (bf16 weights; batch 1 keeps the f32 FMA chain of rounds 1 - 2)
-  constexpr bool DOT2 = std::is_same<T, bf16>::value && !W8 && NB >= 1 && !NO_DOT2;
+  // packed bf16 dot products (v_dot2c_f32_bf16) for every batch size of the bf16 mode, batch 1 included; the f32 and the
+  // split-pair (sp16) builds keep the unpack + f32 FMA chain
+  constexpr bool DOT2 = std::is_same<T, bf16>::value && !W8 && !NO_DOT2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  T* xs = reinterpret_cast<T*>(smem);  // [NB][K]
+  XE* xs = reinterpret_cast<XE*>(smem);  // [NB][K]
   __shared__ float red[NB][8];
   __shared__ float red2[2][4][2][NB];  // PAIR: partial sums of the odd waves, double-buffered over the groups
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -128,7 +133,7 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int b0, int nb) {
 #pragma unroll
       for (int i = 0; i < XV; ++i) {
         const int k = (tid + i * 512) * 4;
-        if (k < K) store4_from_f32<T>(&xs[b * K + k], xv[b][i][0], xv[b][i][1], xv[b][i][2], xv[b][i][3]);  // one LDS store
+        if (k < K) store4_from_f32<XE>(&xs[b * K + k], xv[b][i][0], xv[b][i][1], xv[b][i][2], xv[b][i][3]);  // one LDS store
       }
     }
   } else {
@@ -179,7 +184,7 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int b0, int nb) {
         const int k = (tid + i * 512) * 4;
         if (k < K) {
           const float4v v = xr[b][i] * scale[b] * gr[i];
-          store4_from_f32<T>(&xs[b * K + k], v[0], v[1], v[2], v[3]);
+          store4_from_f32<XE>(&xs[b * K + k], v[0], v[1], v[2], v[3]);
           // the normalised row itself is an output of the step (last-layer hidden state before lm_head)
           if (a.xn_out && blockIdx.x == 0)
             *reinterpret_cast<float4v*>(a.xn_out + (int64_t)(a.xn_row_map ? a.xn_row_map[b0 + b] : b0 + b) * a.xn_ld + k) = v;
@@ -227,11 +232,11 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int b0, int nb) {
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
           if (b < nb) {
-            constexpr int XV = Vec16<T>::N;  // x elements per 16-byte LDS read
+            constexpr int XV = Vec16<XE>::N;  // x elements per 16-byte LDS read
 #pragma unroll
             for (int h = 0; h < VN / XV; ++h) {
               const uint4v xv = *reinterpret_cast<const uint4v*>(&xs[b * K + k + h * XV]);
-              Vec16<T>::unpack(xv, &xf[b][h * XV]);
+              Vec16<XE>::unpack(xv, &xf[b][h * XV]);
             }
           } else {
 #pragma unroll
@@ -242,7 +247,7 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int b0, int nb) {
         for (int r = 0; r < RW; ++r) {
           float wf[VN];
           if constexpr (W8) unpack_fp8x16(wcur[u][r], wf);
-          else Vec16<T>::unpack(wcur[u][r], wf);
+          else Vec16<WE>::unpack(wcur[u][r], wf);
 #pragma unroll
           for (int b = 0; b < NB; ++b)
 #pragma unroll
@@ -334,7 +339,7 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int b0, int nb) {
 template <typename T, int NB>
 static void gemv_dispatch(const GemvArgs& a_in, int b0, int nb, hipStream_t s) {
   GemvArgs a = a_in;
-  const size_t lds = (size_t)NB * a.K * sizeof(T);
+  const size_t lds = (size_t)NB * a.K * (is_split<T>::value ? 4 : sizeof(T));
   if (lds > 150 * 1024) throw std::runtime_error("gemv: K too large for the LDS activation stage");
   // one or two 8-wave workgroups per CU depending on the LDS the activation stage needs
   // (512 workgroups measured best for N*K of 34-262 MB; 256 / 1024 / 2048 were 3-30 % slower)
@@ -345,11 +350,11 @@ static void gemv_dispatch(const GemvArgs& a_in, int b0, int nb, hipStream_t s) {
   auto go = [&](auto xpt_tag) {
     constexpr int XPT = decltype(xpt_tag)::value;
     // algorithmic bytes: every weight element once (+ the tiny activation / output vectors)
-    const double wsz = a.w_fp8 ? 1.0 : (double)sizeof(T);
+    const double wsz = a.w_fp8 ? 1.0 : (is_split<T>::value ? 2.0 : (double)sizeof(T));
     const double wbytes = (double)a.N * a.K * wsz * (a.W2 ? 2 : 1) + (double)nb * (a.K + a.N) * 4;
     // one tag per kernel instantiation, so a tag's average can be checked against rocprofv3's per-kernel one
     char tag[40];
-    snprintf(tag, sizeof(tag), "gemv_%s%s_x%d", a.w_fp8 ? "fp8w" : (sizeof(T) == 2 ? "bf16" : "f32"),
+    snprintf(tag, sizeof(tag), "gemv_%s%s_x%d", a.w_fp8 ? "fp8w" : (is_split<T>::value ? "sp16" : sizeof(T) == 2 ? "bf16" : "f32"),
              a.W2 ? "_swiglu" : "", XPT);
     ProfScope prof(tag, 2.0 * nb * a.N * (double)a.K * (a.W2 ? 2 : 1), wbytes, s);
     if (g_stamp && g_stamp->on) a.stamp = g_stamp->slot(tag, wbytes, grid);
@@ -395,7 +400,7 @@ static void gemv_dispatch(const GemvArgs& a_in, int b0, int nb, hipStream_t s) {
 
 template <typename T>
 void launch_gemv(const GemvArgs& a, hipStream_t s) {
-  const int VN = a.w_fp8 ? 16 : Vec16<T>::N;
+  const int VN = a.w_fp8 ? 16 : Vec16<std::conditional_t<is_split<T>::value, bf16, T>>::N;
   if (a.K % VN || ((uintptr_t)a.W & 15)) throw std::runtime_error("gemv: K must be a multiple of 16 bytes");
   if (a.w_fp8 && (sizeof(T) != 2 || !a.wscale || (a.W2 && !a.wscale2)))
     throw std::runtime_error("gemv: fp8 weights need the bf16 mode and per-row scales");
@@ -444,5 +449,6 @@ void launch_gemv_skinny_f32(const GemvArgs& a, hipStream_t s) {
   else go(std::integral_constant<int, 8>());
 }
 template void launch_gemv<bf16>(const GemvArgs&, hipStream_t);
+template void launch_gemv<sp16>(const GemvArgs&, hipStream_t);
 
 }  // namespace anyref

@@ -257,6 +257,9 @@ struct AttnArgs {
   const void* rel_tab_w = nullptr;
   int rel_tab_ld = 0;
   int o_f32 = 0;  // 1: O is f32 instead of T (decode step feeds the f32 GEMV)
+  // 1 (T = float only): O is a split-pair matrix (common.h sp16: the A operand of the GEMM that follows in
+  // ANYREF_MODE_PARITY16); o_bs / o_rs are whole matrix rows (multiples of 64 elements), o_hs % 4 == 0
+  int o_split = 0;
   int max_wg = 0;  // > 0: at most this many workgroups (bf16, head dim 80, the SAM forms); each walks several blocks
   // set by the launcher: keys split over kv_splits workgroups per query block, partials merged afterwards
   int kv_splits = 1;
@@ -302,6 +305,8 @@ void launch_im2col_3x3(const void* in, int B, int g, int C, void* out, hipStream
 template <typename T>
 void launch_convert(const float* in, int64_t ld_in, void* out, int64_t ld_out, int rows, int cols,
                     hipStream_t s);
+// split-pair (sp16) rows -> f32: out[r, c] = hi + lo; ld_in in sp16 elements (a multiple of 64)
+void launch_unsplit(const void* in, int64_t ld_in, float* out, int64_t ld_out, int rows, int cols, hipStream_t s);
 // out[m, :] = a[m, :] + b[m % bmod, :]   (f32; position embeddings, keys+pe ...)
 void launch_add_rows(const float* a, const float* b, int bmod, float* out, int M, int D, hipStream_t s);
 template <typename T>

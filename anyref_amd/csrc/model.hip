@@ -95,6 +95,19 @@ void ModelBase::drop_raw() {
 // Model<T>
 // =============================================================================================
 constexpr int kRowPadBytes = 128;  // see Lin::ld
+// Storage roles of an arithmetic mode.  T names the GEMM A-operand (activation) type; W is what the weights are packed as,
+// Q what the attention kernels read (q / k / v rows, the KV cache).  float / bf16 / f16: all three are T.  sp16
+// (ANYREF_MODE_PARITY16): activations as split bf16 pairs, weights bf16 exactly as stored, attention operands f32.
+template <typename T>
+struct ModeTypes {
+  using W = T;
+  using Q = T;
+};
+template <>
+struct ModeTypes<sp16> {
+  using W = bf16;
+  using Q = float;
+};
 template <typename T>
 struct Lin {  // nn.Linear packed in T
   T* w = nullptr;
@@ -127,6 +140,20 @@ struct Affine {
 template <typename T, typename TS = T>
 class Model : public ModelBase {
  public:
+  using W = typename ModeTypes<T>::W;    // LLaMA / CLIP / audio weights
+  using Q = typename ModeTypes<T>::Q;    // ... attention operands and the KV cache
+  using WS = typename ModeTypes<TS>::W;  // SAM encoder weights
+  using QS = typename ModeTypes<TS>::Q;  // ... attention operands
+  static constexpr bool SPT = is_split<T>::value, SPS = is_split<TS>::value;
+  static constexpr bool IS16 = sizeof(T) == 2 || SPT;    // the 16-bit MFMA paths (bf16 or split pairs)
+  static constexpr bool IS16S = sizeof(TS) == 2 || SPS;
+  // the q / k / v projections write the attention operand type: f32 in the f32 and the split-pair modes
+  static constexpr bool QF32 = std::is_same<Q, float>::value, QF32S = std::is_same<QS, float>::value;
+  // row stride of an A-operand matrix with `k` logical columns: split-pair rows are whole 64-column blocks
+  template <typename E>
+  static int apad(int k) {
+    return is_split<E>::value ? round_up(k, 64) : k;
+  }
   Model(const anyref_config& c, int device) : ModelBase(c, device) {
     fp8w_ = c.mode == ANYREF_MODE_PERF_FP8W;
     if (fp8w_ && sizeof(T) != 2) throw std::runtime_error("fp8 weights need the bf16 compute mode");
@@ -153,6 +180,7 @@ class Model : public ModelBase {
       if (e) (void)hipEventDestroy(e);
   }
   const char* mode_name() const override {
+    if (SPT) return "f32 activations as bf16 pairs x bf16 weights";
     return sizeof(T) == 2 ? (fp8w_ ? (is_half16<TS>::value ? "bf16+fp8w, SAM f16" : "bf16+fp8w")
                                    : (is_half16<TS>::value ? "bf16, SAM f16" : "bf16"))
                           : "f32";
@@ -189,7 +217,7 @@ class Model : public ModelBase {
   std::vector<float> to_host(const std::string& name);
   template <typename E>
   E* pack_rows(E* dst, int dst_row0, const std::string& name, int rows, int cols, int kpad);
-  template <typename E = T>
+  template <typename E = W>
   Lin<E> pack_linear(const std::string& wname, const std::string& bname, int n, int k, int kalign = 8,
                      int rowpad = 0);
   LinF pack_linear_f32(const std::string& wname, const std::string& bname, int n, int k);
@@ -199,12 +227,21 @@ class Model : public ModelBase {
   U* talloc(size_t n) {
     return reinterpret_cast<U*>(dalloc(n * sizeof(U)));
   }
+  // an A-operand (activation) matrix [rows, width]; split-pair matrices are zeroed once: the columns that pad a row to
+  // whole 64-blocks are never written and meet zero weight columns
+  template <typename U>
+  U* aalloc(size_t rows, int width) {
+    const size_t n = rows * (size_t)apad<U>(width);
+    U* p = talloc<U>(n);
+    if (is_split<U>::value) HIP_TRY(hipMemset(p, 0, n * sizeof(U)));
+    return p;
+  }
 
   // ---- op helpers ----
   // nrm / nrm_out: RMSNorm (gain nrm->g, llm eps) of the output rows written to nrm_out as T when the GEMM
   // takes its split-K path; returns whether that happened (else the caller runs the norm itself)
   template <typename E>
-  bool gemm(hipStream_t s, const E* A, int lda, const Lin<E>& l, void* C, int ldc, int M, int act, bool c_f32,
+  bool gemm(hipStream_t s, const E* A, int lda, const Lin<typename ModeTypes<E>::W>& l, void* C, int ldc, int M, int act, bool c_f32,
             const float* resid = nullptr, int ldr = 0, const int* row_map = nullptr, const Affine* nrm = nullptr,
             void* nrm_out = nullptr, bool swiglu = false, float ln_eps = -1.f, const int* a_row_map = nullptr) {  // nrm_out: E rows
     // nrm / nrm_out: the norm that follows (RMSNorm with the LLM's eps; LayerNorm with ln_eps when ln_eps >= 0) is
@@ -219,11 +256,13 @@ class Model : public ModelBase {
         a.norm_eps = ln_eps;
       }
     }
-    a.A = A; a.lda = lda; a.W = l.w; a.ldw = l.stride(); a.bias = l.b; a.C = C; a.ldc = ldc; a.M = M; a.N = l.n;
+    a.A = A; a.lda = apad<E>(lda); a.W = l.w; a.ldw = l.stride(); a.bias = l.b; a.C = C; a.ldc = c_f32 ? ldc : apad<E>(ldc);
+    a.M = M; a.N = l.n;
+    a.norm_ld = apad<E>(a.norm_ld);
     a.K = l.k; a.act = act; a.c_f32 = c_f32 ? 1 : 0; a.resid = resid; a.ldr = ldr; a.row_map = row_map;
     a.a_row_map = a_row_map;
     a.max_wg = cap_wg_;
-    if constexpr (std::is_same<E, T>::value) {
+    if constexpr (std::is_same<E, T>::value && !SPT) {
       if (l.w8) {
         if (l.k % 64 == 0) {  // fp8 bytes straight into the GEMM (widened to bf16 per fragment, scale in the epilogue)
           a.W = l.w8; a.w_fp8 = 1; a.col_scale = l.ws;
@@ -243,7 +282,7 @@ class Model : public ModelBase {
   // workgroups (one round on the free CUs) a co-running step takes 3.97 -> 3.85 ms (image 39.8 - 40.3 -> 39.5 - 40.1 on one
   // box; 384 with the wave-pair kernels unbalanced: 4.1); alone 512 stays better (2.77 vs 2.89 ms).  Same sums either way.
   int gemv_grid_ = 0;
-  void gemv_w(GemvArgs& g, const Lin<T>& l, int row0 = 0) const {
+  void gemv_w(GemvArgs& g, const Lin<W>& l, int row0 = 0) const {
     g.ldw = l.stride();
     g.grid = gemv_grid_;
     if (l.w8) {
@@ -254,7 +293,7 @@ class Model : public ModelBase {
       g.W = l.w + (size_t)row0 * l.stride();
     }
   }
-  void gemv_w2(GemvArgs& g, const Lin<T>& l, int row0) const {
+  void gemv_w2(GemvArgs& g, const Lin<W>& l, int row0) const {
     if (l.w8) {
       g.W2 = l.w8 + (size_t)row0 * l.stride();
       g.wscale2 = l.ws + row0;
@@ -263,19 +302,19 @@ class Model : public ModelBase {
     }
   }
   bool fp8w_ = false;
-  T* deq_buf_ = nullptr;  // bf16 image of the largest fp8 weight (prefill operand)
+  W* deq_buf_ = nullptr;  // bf16 image of the largest fp8 weight (prefill operand)
   // pack rows of a raw f32 tensor as fp8 + scales into l (rows [row0, row0 + rows))
   // rstride 2: every second row of l (gate / up interleave), starting at row0
-  void pack_rows_fp8(Lin<T>& l, int row0, const std::string& name, int rows, int cols, int rstride = 1) {
+  void pack_rows_fp8(Lin<W>& l, int row0, const std::string& name, int rows, int cols, int rstride = 1) {
     const RawTensor& t = raw(name);
     if (t.numel() != (int64_t)rows * cols || cols != l.k)
       throw std::runtime_error("shape mismatch for " + name + " (fp8 pack)");
     launch_quant_fp8_rows(t.p, cols, rows, cols, l.w8 + (size_t)row0 * l.stride(), l.stride() * rstride, l.ws + row0, 0,
                           rstride);
   }
-  Lin<T> alloc_fp8(int n, int k) {
+  Lin<W> alloc_fp8(int n, int k) {
     if (k % 16) throw std::runtime_error("fp8 weights need K % 16 == 0");
-    Lin<T> l;
+    Lin<W> l;
     l.n = n;
     l.k = k;
     l.ld = k + kRowPadBytes;
@@ -304,7 +343,7 @@ class Model : public ModelBase {
   void norm(hipStream_t s, const float* x, int ldx, const Affine& af, void* y, int ldy, int M, int D, float eps,
             bool y_f32, bool rms = false, const int* row_map = nullptr, int act = ACT_NONE) {
     NormArgs a;
-    a.x = x; a.ldx = ldx; a.gain = af.g; a.bias = af.b; a.y = y; a.ldy = ldy; a.M = M; a.D = D; a.eps = eps;
+    a.x = x; a.ldx = ldx; a.gain = af.g; a.bias = af.b; a.y = y; a.ldy = y_f32 ? ldy : apad<E>(ldy); a.M = M; a.D = D; a.eps = eps;
     a.rms = rms ? 1 : 0; a.y_f32 = y_f32 ? 1 : 0; a.row_map = row_map; a.act = act;
     launch_norm<E>(a, s);
   }
@@ -370,34 +409,36 @@ class Model : public ModelBase {
   // ---- CLIP ----
   struct ClipLayer {
     Affine ln1, ln2;
-    Lin<T> qkv, out, fc1, fc2;
+    Lin<W> qkv, out, fc1, fc2;
   };
   int clip_n_ = 0, clip_kp_ = 0;
-  Lin<T> clip_patch_;
+  Lin<W> clip_patch_;
   float *clip_cls_ = nullptr, *clip_pos_ = nullptr;
   Affine clip_pre_;
   std::vector<ClipLayer> clip_layers_;
-  Lin<T> mm_proj_;
-  T *c_col_ = nullptr, *c_h_ = nullptr, *c_qkv_ = nullptr, *c_att_ = nullptr, *c_mlp_ = nullptr, *c_feat_ = nullptr;
+  Lin<W> mm_proj_;
+  T *c_col_ = nullptr, *c_h_ = nullptr, *c_att_ = nullptr, *c_mlp_ = nullptr, *c_feat_ = nullptr;
+  Q* c_qkv_ = nullptr;
   float *c_patch_ = nullptr, *c_x_ = nullptr, *img_feat_ = nullptr;
 
   // ---- LLM ----
   struct LlmLayer {
     Affine in_norm, post_norm;
-    Lin<T> qkv, o, gu, down;
-    T *gate_w = nullptr, *up_w = nullptr;  // views into gu.w
+    Lin<W> qkv, o, gu, down;
+    W *gate_w = nullptr, *up_w = nullptr;  // views into gu.w
   };
-  T* emb_table_ = nullptr;
+  W* emb_table_ = nullptr;
   std::vector<LlmLayer> llm_layers_;
   Affine llm_norm_;
-  Lin<T> lm_head_;
+  Lin<W> lm_head_;
   float* rope_tab_ = nullptr;
-  T *kcache_ = nullptr, *vcache_ = nullptr, *q_last_ = nullptr;
+  Q *kcache_ = nullptr, *vcache_ = nullptr, *q_last_ = nullptr;
   size_t cache_layer_stride_ = 0;
   float *l_x_ = nullptr, *hidden_all_ = nullptr, *l_logits_ = nullptr, *l_xlast_ = nullptr;
-  T *l_h_ = nullptr, *l_qkv_ = nullptr, *l_q_ = nullptr, *l_att_ = nullptr, *l_act_ = nullptr;
+  T *l_h_ = nullptr, *l_att_ = nullptr, *l_act_ = nullptr;
+  Q *l_qkv_ = nullptr, *l_q_ = nullptr;
   float *d_x_ = nullptr, *d_qkv_ = nullptr, *d_att_ = nullptr, *d_act_ = nullptr;
-  T* d_q_ = nullptr;
+  Q* d_q_ = nullptr;
   int64_t *ids_dev_ = nullptr, *next_dev_ = nullptr;
   float* qkv_slabs_ = nullptr;  // [2][<= 320][3H] f32: the two K slices of the prefill qkv projection
   bool qkv_slabs_off_ = getenv("ANYREF_NO_QKV_SLABS") != nullptr;
@@ -427,41 +468,42 @@ class Model : public ModelBase {
   // ---- ImageBind audio trunk (f-4; present iff cfg.aud_blocks > 0) ----
   struct AudBlock {
     Affine ln1, ln2;
-    Lin<T> qkv, out, fc1, fc2;
+    Lin<W> qkv, out, fc1, fc2;
     float *bias_k = nullptr, *bias_v = nullptr;
   };
   std::vector<AudBlock> aud_blocks_;
-  Lin<T> aud_stem_, aud_head_;
+  Lin<W> aud_stem_, aud_head_;
   Affine aud_stem_ln_, aud_head_ln_;
   float *aud_cls_ = nullptr, *aud_pos_ = nullptr, aud_scale_ = 20.f;
   int aud_np_ = 0, aud_rows_ = 0;   // patches per clip; rows per clip in the work buffers (tokens + 1 spare)
   int* aud_kvrow_ = nullptr;        // the spare row of every clip (holds bias_k / bias_v as the extra key / value)
-  T *a_col_ = nullptr, *a_h_ = nullptr, *a_qkv_ = nullptr, *a_att_ = nullptr, *a_mlp_ = nullptr, *a_clsrow_ = nullptr;
+  T *a_col_ = nullptr, *a_h_ = nullptr, *a_att_ = nullptr, *a_mlp_ = nullptr, *a_clsrow_ = nullptr;
+  Q* a_qkv_ = nullptr;
   float *a_patch_ = nullptr, *a_x_ = nullptr, *a_emb_ = nullptr;
 
   // ---- glue ----
   LinF fc1_, fc2_;
-  Lin<T> audio_proj_;
+  Lin<W> audio_proj_;
   bool has_audio_ = false;
   float *seg_h_ = nullptr, *seg_t_ = nullptr, *pred_emb_ = nullptr, *attn_row_ = nullptr;
 
   // ---- SAM encoder ----
   struct SamBlock {
     Affine ln1, ln2;
-    Lin<TS> qkv, proj, lin1, lin2;
-    Lin<TS> rel;  // [2*Np, hd]: rows [0,2sz-1) = rel_pos_h, rows [Np, Np+2sz-1) = rel_pos_w, Np = 2*sz
+    Lin<WS> qkv, proj, lin1, lin2;
+    Lin<QS> rel;  // (multiplied with q rows: the attention operand type) [2*Np, hd]: rows [0,2sz-1) = rel_pos_h, rows [Np, Np+2sz-1) = rel_pos_w, Np = 2*sz
     bool global = false;
   };
-  Lin<TS> sam_patch_;
+  Lin<WS> sam_patch_;
   float* sam_pos_ = nullptr;
   std::vector<SamBlock> sam_blocks_;
-  Lin<TS> neck0_, neck2_;
+  Lin<WS> neck0_, neck2_;
   Affine neck1_, neck3_;
   int sam_g_ = 0, sam_nw_ = 0, sam_wrows_ = 0;  // grid, windows per side, window-layout rows per image
   int *win2tok_ = nullptr, *tok2win_ = nullptr, *pad_rows_ = nullptr;  // pad_rows_: window-layout rows with no token
   int n_pad_rows_ = 0;                                                  // per image
-  TS *s_col_ = nullptr, *s_hglob_ = nullptr, *s_qkv_ = nullptr, *s_att_ = nullptr,
-     *s_mlp_ = nullptr, *s_n1_ = nullptr, *s_col3_ = nullptr;
+  TS *s_col_ = nullptr, *s_hglob_ = nullptr, *s_att_ = nullptr, *s_mlp_ = nullptr, *s_n1_ = nullptr, *s_col3_ = nullptr;
+  QS* s_qkv_ = nullptr;
   float *s_x_ = nullptr, *s_relh_ = nullptr, *s_relw_ = nullptr, *s_n0_ = nullptr, *s_n2_ = nullptr,
         *sam_emb_ = nullptr;
 
@@ -527,6 +569,7 @@ Lin<E> Model<T, TS>::pack_linear(const std::string& wname, const std::string& bn
                                  int rowpad) {
   Lin<E> l;
   l.n = n;
+  if (SPT || SPS) kalign = std::max(kalign, 64);  // split-pair A rows come in whole 64-column blocks (zero weight columns)
   l.k = round_up(k, kalign);
   l.ld = l.k + rowpad;
   l.w = talloc<E>((size_t)n * l.ld);
@@ -612,7 +655,8 @@ void Model<T, TS>::finalize() {
       L.ln2 = affine(lp + "layer_norm2");
       L.qkv.n = 3 * Dc;
       L.qkv.k = Dc;
-      L.qkv.w = talloc<T>((size_t)3 * Dc * Dc);
+      if (SPT && Dc % 64) throw std::runtime_error("parity16: clip_dim must be a multiple of 64");
+      L.qkv.w = talloc<W>((size_t)3 * Dc * Dc);
       L.qkv.b = talloc<float>(3 * Dc);
       const char* names[3] = {"q_proj", "k_proj", "v_proj"};
       for (int j = 0; j < 3; ++j) {
@@ -626,14 +670,14 @@ void Model<T, TS>::finalize() {
     }
     mm_proj_ = pack_linear("model.mm_projector.weight", "model.mm_projector.bias", c.llm_dim, Dc);
     const size_t R = (size_t)MB * (clip_n_ + 1);
-    c_col_ = talloc<T>((size_t)MB * clip_n_ * clip_kp_);
+    c_col_ = aalloc<T>((size_t)MB * clip_n_, clip_kp_);
     c_patch_ = talloc<float>((size_t)MB * clip_n_ * Dc);
     c_x_ = talloc<float>(R * Dc);
-    c_h_ = talloc<T>(R * Dc);
-    c_qkv_ = talloc<T>(R * 3 * Dc);
-    c_att_ = talloc<T>(R * Dc);
-    c_mlp_ = talloc<T>(R * c.clip_mlp);
-    c_feat_ = talloc<T>((size_t)MB * clip_n_ * Dc);
+    c_h_ = aalloc<T>(R, Dc);
+    c_qkv_ = talloc<Q>(R * 3 * Dc);
+    c_att_ = aalloc<T>(R, Dc);
+    c_mlp_ = aalloc<T>(R, c.clip_mlp);
+    c_feat_ = aalloc<T>((size_t)MB * clip_n_, Dc);
     img_feat_ = talloc<float>((size_t)MB * clip_n_ * c.llm_dim);
   }
   // ================= LLaMA =================
@@ -641,7 +685,8 @@ void Model<T, TS>::finalize() {
     const int H = c.llm_dim, F = c.llm_mlp, V = c.llm_vocab, S = c.llm_max_seq, nh = c.llm_heads, hd = H / nh;
     if (raw("model.embed_tokens.weight").numel() != (int64_t)V * H)
       throw std::runtime_error("embed_tokens shape mismatch (vocab/dim)");
-    emb_table_ = talloc<T>((size_t)V * H);
+    if (SPT && H % 64) throw std::runtime_error("parity16: llm_dim must be a multiple of 64");
+    emb_table_ = talloc<W>((size_t)V * H);
     pack_rows(emb_table_, 0, "model.embed_tokens.weight", V, H, H);
     llm_layers_.resize(c.llm_layers);
     for (int i = 0; i < c.llm_layers; ++i) {
@@ -661,25 +706,25 @@ void Model<T, TS>::finalize() {
         L.down = alloc_fp8(H, F);
         pack_rows_fp8(L.down, 0, lp + "mlp.down_proj.weight", H, F);
       } else {
-        const int rp = kRowPadBytes / (int)sizeof(T), ldh = H + rp;
+        const int rp = kRowPadBytes / (int)sizeof(W), ldh = H + rp;
         L.qkv.n = 3 * H;
         L.qkv.k = H;
         L.qkv.ld = ldh;
-        L.qkv.w = talloc<T>((size_t)3 * H * ldh);
-        HIP_TRY(hipMemset(L.qkv.w, 0, (size_t)3 * H * ldh * sizeof(T)));
+        L.qkv.w = talloc<W>((size_t)3 * H * ldh);
+        HIP_TRY(hipMemset(L.qkv.w, 0, (size_t)3 * H * ldh * sizeof(W)));
         for (int j = 0; j < 3; ++j) pack_rows(L.qkv.w, j * H, lp + "self_attn." + names[j] + ".weight", H, H, ldh);
         L.o = pack_linear(lp + "self_attn.o_proj.weight", "", H, H, 8, rp);
         L.gu.n = 2 * F;
         L.gu.k = H;
         L.gu.ld = ldh;
-        L.gu.w = talloc<T>((size_t)2 * F * ldh);  // rows interleaved: 2j = gate_j, 2j + 1 = up_j
-        HIP_TRY(hipMemset(L.gu.w, 0, (size_t)2 * F * ldh * sizeof(T)));
+        L.gu.w = talloc<W>((size_t)2 * F * ldh);  // rows interleaved: 2j = gate_j, 2j + 1 = up_j
+        HIP_TRY(hipMemset(L.gu.w, 0, (size_t)2 * F * ldh * sizeof(W)));
         pack_rows(L.gu.w, 0, lp + "mlp.gate_proj.weight", F, H, 2 * ldh);
         pack_rows(L.gu.w + ldh, 0, lp + "mlp.up_proj.weight", F, H, 2 * ldh);
         L.gate_w = L.gu.w;
         L.up_w = L.gu.w + ldh;
         L.down = pack_linear(lp + "mlp.down_proj.weight", "", H, F, 8, rp);
-        if (L.down.k != F) throw std::runtime_error("llm_mlp must be a multiple of 8");
+        if (F % 8) throw std::runtime_error("llm_mlp must be a multiple of 8");
       }
       // free the raw copies of this layer early (7B in f32 is 27 GB)
       HIP_TRY(hipStreamSynchronize(0));
@@ -698,9 +743,9 @@ void Model<T, TS>::finalize() {
       lm_head_ = alloc_fp8(V, H);
       pack_rows_fp8(lm_head_, 0, "lm_head.weight", V, H);
       const size_t big = std::max((size_t)2 * F * H, std::max((size_t)3 * H * H, (size_t)V * H));
-      deq_buf_ = talloc<T>(big);
+      deq_buf_ = talloc<W>(big);
     } else {
-      lm_head_ = pack_linear("lm_head.weight", "", V, H, 8, kRowPadBytes / (int)sizeof(T));
+      lm_head_ = pack_linear("lm_head.weight", "", V, H, 8, kRowPadBytes / (int)sizeof(W));
     }
     // rotary table, same fp32 op order as HF LlamaRotaryEmbedding
     std::vector<float> tab((size_t)S * hd);
@@ -713,24 +758,24 @@ void Model<T, TS>::finalize() {
       }
     rope_tab_ = upload_f32(tab);
     cache_layer_stride_ = (size_t)MB * S * H;
-    kcache_ = talloc<T>(cache_layer_stride_ * c.llm_layers);
-    vcache_ = talloc<T>(cache_layer_stride_ * c.llm_layers);
+    kcache_ = talloc<Q>(cache_layer_stride_ * c.llm_layers);
+    vcache_ = talloc<Q>(cache_layer_stride_ * c.llm_layers);
     const size_t R = (size_t)MB * S;
     l_x_ = talloc<float>(R * H);
     hidden_all_ = talloc<float>(R * H);
-    l_h_ = talloc<T>(R * H);
-    l_qkv_ = talloc<T>(R * 3 * H);
+    l_h_ = aalloc<T>(R, std::max(H, c.audio_dim));  // (project_audio stages its input rows here)
+    l_qkv_ = talloc<Q>(R * 3 * H);
     if (sizeof(T) == 2 && (size_t)3 * H / 96 * 2 <= 256) qkv_slabs_ = talloc<float>((size_t)2 * 320 * 3 * H);  // prefill qkv K slices (R <= 320)
-    l_q_ = talloc<T>(R * H);
-    l_att_ = talloc<T>(R * H);
-    l_act_ = talloc<T>(R * F);
+    l_q_ = talloc<Q>(R * H);
+    l_att_ = aalloc<T>(R, H);
+    l_act_ = aalloc<T>(R, F);
     l_logits_ = talloc<float>((size_t)MB * V);
     l_xlast_ = talloc<float>((size_t)MB * H);
     d_x_ = talloc<float>((size_t)MB * H);
     d_qkv_ = talloc<float>((size_t)MB * 3 * H);
     d_att_ = talloc<float>((size_t)MB * H);
     d_act_ = talloc<float>((size_t)MB * F);
-    d_q_ = talloc<T>((size_t)MB * H);
+    d_q_ = talloc<Q>((size_t)MB * H);
     ids_dev_ = talloc<int64_t>((size_t)MB * S);
     next_dev_ = talloc<int64_t>(MB);
     lens_dev_ = talloc<int>(MB);
@@ -775,7 +820,8 @@ void Model<T, TS>::finalize() {
     sam_g_ = g;
     sam_nw_ = cdiv(g, ws);
     sam_wrows_ = sam_nw_ * sam_nw_ * ws * ws;
-    sam_patch_ = pack_linear<TS>(p + "patch_embed.proj.weight", p + "patch_embed.proj.bias", D, 3 * c.sam_patch * c.sam_patch);
+    if (SPS && (D % 64 || C % 64)) throw std::runtime_error("parity16: sam_dim / sam_out_chans must be multiples of 64");
+    sam_patch_ = pack_linear<WS>(p + "patch_embed.proj.weight", p + "patch_embed.proj.bias", D, 3 * c.sam_patch * c.sam_patch);
     if (raw(p + "pos_embed").numel() != (int64_t)g * g * D) throw std::runtime_error("pos_embed shape mismatch");
     sam_pos_ = own_f32(p + "pos_embed");
     sam_blocks_.resize(c.sam_depth);
@@ -786,10 +832,10 @@ void Model<T, TS>::finalize() {
         if (c.sam_global_idx[j] == i) L.global = true;
       L.ln1 = affine(bp + "norm1");
       L.ln2 = affine(bp + "norm2");
-      L.qkv = pack_linear<TS>(bp + "attn.qkv.weight", bp + "attn.qkv.bias", 3 * D, D);
-      L.proj = pack_linear<TS>(bp + "attn.proj.weight", bp + "attn.proj.bias", D, D);
-      L.lin1 = pack_linear<TS>(bp + "mlp.lin1.weight", bp + "mlp.lin1.bias", c.sam_mlp_ratio * D, D);
-      L.lin2 = pack_linear<TS>(bp + "mlp.lin2.weight", bp + "mlp.lin2.bias", D, c.sam_mlp_ratio * D);
+      L.qkv = pack_linear<WS>(bp + "attn.qkv.weight", bp + "attn.qkv.bias", 3 * D, D);
+      L.proj = pack_linear<WS>(bp + "attn.proj.weight", bp + "attn.proj.bias", D, D);
+      L.lin1 = pack_linear<WS>(bp + "mlp.lin1.weight", bp + "mlp.lin1.bias", c.sam_mlp_ratio * D, D);
+      L.lin2 = pack_linear<WS>(bp + "mlp.lin2.weight", bp + "mlp.lin2.bias", D, c.sam_mlp_ratio * D);
       const int sz = L.global ? g : ws;
       // a table of another length (checkpoint trained at another window / image size) is resampled once, here
       resample_rel_pos(bp + "attn.rel_pos_h", 2 * sz - 1, hd);
@@ -800,12 +846,12 @@ void Model<T, TS>::finalize() {
       const int kp = round_up(hd, 64) <= 3 * D - (nh_sam - 1) * hd ? round_up(hd, 64) : hd;
       L.rel.n = 2 * Np;
       L.rel.k = kp;
-      L.rel.w = talloc<TS>((size_t)2 * Np * kp);
-      HIP_TRY(hipMemset(L.rel.w, 0, (size_t)2 * Np * kp * sizeof(TS)));
+      L.rel.w = talloc<QS>((size_t)2 * Np * kp);
+      HIP_TRY(hipMemset(L.rel.w, 0, (size_t)2 * Np * kp * sizeof(QS)));
       pack_rows(L.rel.w, 0, bp + "attn.rel_pos_h", 2 * sz - 1, hd, kp);
       pack_rows(L.rel.w, Np, bp + "attn.rel_pos_w", 2 * sz - 1, hd, kp);
     }
-    neck0_ = pack_linear<TS>(p + "neck.0.weight", "", C, D);
+    neck0_ = pack_linear<WS>(p + "neck.0.weight", "", C, D);
     neck1_ = affine(p + "neck.1");
     neck3_ = affine(p + "neck.3");
     {  // 3x3 conv weight [O][C][3][3] -> [O][(ky*3+kx)*C + c]
@@ -817,8 +863,8 @@ void Model<T, TS>::finalize() {
       float* rf = upload_f32(r);
       neck2_.n = C;
       neck2_.k = 9 * C;
-      neck2_.w = talloc<TS>(r.size());
-      launch_convert<TS>(rf, 9 * C, neck2_.w, 9 * C, C, 9 * C, 0);
+      neck2_.w = talloc<WS>(r.size());
+      launch_convert<WS>(rf, 9 * C, neck2_.w, 9 * C, C, 9 * C, 0);
       HIP_TRY(hipStreamSynchronize(0));
       dfree(rf);
     }
@@ -853,18 +899,18 @@ void Model<T, TS>::finalize() {
     HIP_TRY(hipMemcpy(win2tok_, w2t.data(), w2t.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(tok2win_, t2w.data(), t2w.size() * 4, hipMemcpyHostToDevice));
     const size_t RT = (size_t)MB * g * g, RW = std::max((size_t)MB * sam_wrows_, RT);
-    s_col_ = talloc<TS>(RT * sam_patch_.k);
+    s_col_ = aalloc<TS>(RT, sam_patch_.k);
     s_x_ = talloc<float>(RT * D);
-    s_hglob_ = talloc<TS>(RT * D);
-    s_qkv_ = talloc<TS>(RW * 3 * D);
-    s_att_ = talloc<TS>(RW * D);
-    s_mlp_ = talloc<TS>(RT * c.sam_mlp_ratio * D);
+    s_hglob_ = aalloc<TS>(RT, D);
+    s_qkv_ = talloc<QS>(RW * 3 * D);
+    s_att_ = aalloc<TS>(RW, D);
+    s_mlp_ = aalloc<TS>(RT, c.sam_mlp_ratio * D);
     const size_t rel_g = (size_t)MB * c.sam_heads * g * g * 4 * g;          // [H][B*g*g][2*Np], Np = 2g
     const size_t rel_w = (size_t)MB * sam_wrows_ * c.sam_heads * 4 * ws;     // [H][B*wrows][2*Np], Np = 2ws
     s_relh_ = talloc<float>(std::max(rel_g, rel_w));
     s_n0_ = talloc<float>(RT * C);
-    s_n1_ = talloc<TS>(RT * C);
-    s_col3_ = talloc<TS>(RT * 9 * C);
+    s_n1_ = aalloc<TS>(RT, C);
+    s_col3_ = aalloc<TS>(RT, 9 * C);
     s_n2_ = talloc<float>(RT * C);
     sam_emb_ = talloc<float>(RT * C);
   }
@@ -1005,15 +1051,16 @@ void Model<T, TS>::finalize() {
     aud_scale_ = std::min(expf(ls.at(0)), 100.f);  // LearnableLogitScaling: clip(exp(log_scale), max = 100)
     const int NC = c.aud_clips * MB;
     const size_t Rr = (size_t)NC * aud_rows_;
-    a_col_ = talloc<T>((size_t)NC * aud_np_ * k * k);
+    if (SPT && D % 64) throw std::runtime_error("parity16: aud_dim must be a multiple of 64");
+    a_col_ = aalloc<T>((size_t)NC * aud_np_, k * k);
     a_patch_ = talloc<float>((size_t)NC * aud_np_ * D);
     a_x_ = talloc<float>(Rr * D);
-    a_h_ = talloc<T>(Rr * D);
-    a_qkv_ = talloc<T>(Rr * 3 * D);
-    a_att_ = talloc<T>(Rr * D);
+    a_h_ = aalloc<T>(Rr, D);
+    a_qkv_ = talloc<Q>(Rr * 3 * D);
+    a_att_ = aalloc<T>(Rr, D);
     HIP_TRY(hipMemset(a_att_, 0, Rr * D * sizeof(T)));  // the spare rows are never written by the attention
-    a_mlp_ = talloc<T>(Rr * 4 * D);
-    a_clsrow_ = talloc<T>((size_t)NC * D);
+    a_mlp_ = aalloc<T>(Rr, 4 * D);
+    a_clsrow_ = aalloc<T>((size_t)NC, D);
     a_emb_ = talloc<float>((size_t)NC * c.audio_dim);
     std::vector<int> rows(NC);
     for (int i = 0; i < NC; ++i) rows[i] = i * aud_rows_ + aud_np_ + 1;
@@ -1117,7 +1164,7 @@ void Model<T, TS>::decode_step_graph(hipStream_t s, int B, bool keep_q, bool cor
 
 template <typename T, typename TS>
 void Model<T, TS>::ensure_q_last() {
-  if (!q_last_) q_last_ = talloc<T>((size_t)cfg.max_batch * cfg.llm_max_seq * cfg.llm_dim);
+  if (!q_last_) q_last_ = talloc<Q>((size_t)cfg.max_batch * cfg.llm_max_seq * cfg.llm_dim);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1135,7 +1182,7 @@ void Model<T, TS>::clip_tower(hipStream_t s, const float* images, int B) {
   for (size_t li = 0; li < clip_layers_.size(); ++li) {
     auto& L = clip_layers_[li];
     if (!h_ready) norm(s, c_x_, Dc, L.ln1, c_h_, Dc, R, Dc, c.clip_eps, false);
-    gemm(s, c_h_, Dc, L.qkv, c_qkv_, 3 * Dc, R, ACT_NONE, false);
+    gemm(s, c_h_, Dc, L.qkv, c_qkv_, 3 * Dc, R, ACT_NONE, QF32);
     AttnArgs a;
     a.Q = c_qkv_; a.K = c_qkv_ + Dc; a.V = c_qkv_ + 2 * Dc; a.O = c_att_;
     a.q_bs = a.k_bs = a.v_bs = (int64_t)S * 3 * Dc;
@@ -1144,7 +1191,8 @@ void Model<T, TS>::clip_tower(hipStream_t s, const float* images, int B) {
     a.o_bs = (int64_t)S * Dc; a.o_rs = Dc; a.o_hs = hd;
     a.B = B; a.H = c.clip_heads; a.Sq = S; a.Sk = S; a.hd = hd;
     a.scale = 1.f / sqrtf((float)hd);
-    launch_attention<T>(a, s);
+    a.o_split = SPT;
+    launch_attention<Q>(a, s);
     // the two LayerNorms of a block ride on the split-K reductions of the GEMMs in front of them (perf mode)
     if (!gemm(s, c_att_, Dc, L.out, c_x_, Dc, R, ACT_NONE, true, c_x_, Dc, nullptr, &L.ln2, c_h_, false, c.clip_eps))
       norm(s, c_x_, Dc, L.ln2, c_h_, Dc, R, Dc, c.clip_eps, false);
@@ -1154,7 +1202,7 @@ void Model<T, TS>::clip_tower(hipStream_t s, const float* images, int B) {
                    c.clip_eps);
   }
   for (int b = 0; b < B; ++b)  // drop CLS ("patch" feature select)
-    launch_convert<T>(c_x_ + ((size_t)b * S + 1) * Dc, Dc, c_feat_ + (size_t)b * n * Dc, Dc, n, Dc, s);
+    launch_convert<T>(c_x_ + ((size_t)b * S + 1) * Dc, Dc, c_feat_ + (size_t)b * n * apad<T>(Dc), apad<T>(Dc), n, Dc, s);
   gemm(s, c_feat_, Dc, mm_proj_, img_feat_, c.llm_dim, B * n, ACT_NONE, true);
 }
 
@@ -1186,10 +1234,10 @@ void Model<T, TS>::audio_encode(hipStream_t s, const float* mel, int n, float* e
   launch_clip_assemble(a_patch_, aud_cls_, aud_pos_, a_x_, n, np, D, s, RS);
   for (auto& Bk : aud_blocks_) {  // pre-LN blocks (transformer.py:94-170), nn.MultiheadAttention(add_bias_kv=True)
     norm(s, a_x_, D, Bk.ln1, a_h_, D, R, D, 1e-6f, false);
-    gemm(s, a_h_, D, Bk.qkv, a_qkv_, 3 * D, R, ACT_NONE, false);
+    gemm(s, a_h_, D, Bk.qkv, a_qkv_, 3 * D, R, ACT_NONE, QF32);
     // the appended key / value of every clip is the learned bias_k / bias_v row (not projected)
-    launch_fill_rows_bias<T>(a_qkv_ + D, 3 * D, aud_kvrow_, n, Bk.bias_k, D, s);
-    launch_fill_rows_bias<T>(a_qkv_ + 2 * D, 3 * D, aud_kvrow_, n, Bk.bias_v, D, s);
+    launch_fill_rows_bias<Q>(a_qkv_ + D, 3 * D, aud_kvrow_, n, Bk.bias_k, D, s);
+    launch_fill_rows_bias<Q>(a_qkv_ + 2 * D, 3 * D, aud_kvrow_, n, Bk.bias_v, D, s);
     AttnArgs a;
     a.Q = a_qkv_; a.K = a_qkv_ + D; a.V = a_qkv_ + 2 * D; a.O = a_att_;
     a.q_bs = a.k_bs = a.v_bs = (int64_t)RS * 3 * D;
@@ -1198,7 +1246,8 @@ void Model<T, TS>::audio_encode(hipStream_t s, const float* mel, int n, float* e
     a.o_bs = (int64_t)RS * D; a.o_rs = D; a.o_hs = hd;
     a.B = n; a.H = nh; a.Sq = St; a.Sk = St + 1; a.hd = hd;
     a.scale = 1.f / sqrtf((float)hd);
-    launch_attention<T>(a, s);
+    a.o_split = SPT;
+    launch_attention<Q>(a, s);
     gemm(s, a_att_, D, Bk.out, a_x_, D, R, ACT_NONE, true, a_x_, D);
     norm(s, a_x_, D, Bk.ln2, a_h_, D, R, D, 1e-6f, false);
     gemm(s, a_h_, D, Bk.fc1, a_mlp_, 4 * D, R, ACT_GELU, false);
@@ -1216,7 +1265,7 @@ void Model<T, TS>::project_audio(hipStream_t s, const float* audio_emb, int n, f
   if (!has_audio_) throw std::runtime_error("model.audio_projector.* was not provided");
   if (n > cfg.max_batch * 64) throw std::runtime_error("too many audio rows");
   // stage through the LLM scratch (idle at this point)
-  launch_convert<T>(audio_emb, cfg.audio_dim, l_h_, cfg.audio_dim, n, cfg.audio_dim, s);
+  launch_convert<T>(audio_emb, cfg.audio_dim, l_h_, apad<T>(cfg.audio_dim), n, cfg.audio_dim, s);
   gemm(s, l_h_, cfg.audio_dim, audio_proj_, out, cfg.llm_dim, n, ACT_NONE, true);
 }
 
@@ -1233,10 +1282,10 @@ void Model<T, TS>::llm_prefill(hipStream_t s, int B, int Sp, const int* lens_dev
   bool h_ready = false;  // l_h_ already holds in_norm(x) (fused into the previous layer's down_proj reduction)
   for (int i = 0; i < nl; ++i) {
     LlmLayer& L = llm_layers_[i];
-    T* kc = kcache_ + cache_layer_stride_ * i;
-    T* vc = vcache_ + cache_layer_stride_ * i;
+    Q* kc = kcache_ + cache_layer_stride_ * i;
+    Q* vc = vcache_ + cache_layer_stride_ * i;
     if (!h_ready) norm(s, l_x_, H, L.in_norm, l_h_, H, R, H, c.llm_rms_eps, false, true);
-    T* qkeep = (keep_q && i == nl - 1) ? q_last_ : nullptr;
+    Q* qkeep = (keep_q && i == nl - 1) ? q_last_ : nullptr;
     if (qkv_slabs_ && !L.qkv.w8 && R > 192 && R <= 320 && H % 128 == 0 && hd % 16 == 0 && !qkv_slabs_off_) {
       // one image's prompt: the projection as two K slices on whole-M tiles (256 workgroups), summed by the RoPE kernel
       GemmArgs a;
@@ -1246,8 +1295,8 @@ void Model<T, TS>::llm_prefill(hipStream_t s, int B, int Sp, const int* lens_dev
       launch_rope_cache_slabs(qkv_slabs_, qkv_slabs_ + (size_t)R * 3 * H, B, Sp, nh, hd, nullptr, lens_dev, rope_tab_, l_q_, kc,
                               vc, S, qkeep, s);
     } else {
-      gemm(s, l_h_, H, L.qkv, l_qkv_, 3 * H, R, ACT_NONE, false);
-      launch_rope_cache<T>(l_qkv_, B, Sp, nh, hd, nullptr, lens_dev, rope_tab_, l_q_, kc, vc, S, qkeep, s);
+      gemm(s, l_h_, H, L.qkv, l_qkv_, 3 * H, R, ACT_NONE, QF32);
+      launch_rope_cache<Q>(l_qkv_, B, Sp, nh, hd, nullptr, lens_dev, rope_tab_, l_q_, kc, vc, S, qkeep, s);
     }
     AttnArgs a;
     a.Q = l_q_; a.K = kc; a.V = vc; a.O = l_att_;
@@ -1257,7 +1306,8 @@ void Model<T, TS>::llm_prefill(hipStream_t s, int B, int Sp, const int* lens_dev
     a.B = B; a.H = nh; a.Sq = Sp; a.Sk = Sp; a.hd = hd;
     a.scale = 1.f / sqrtf((float)hd);
     a.causal = 1; a.kv_len = lens_dev; a.q_len = lens_dev;
-    launch_attention<T>(a, s);
+    a.o_split = SPT;
+    launch_attention<Q>(a, s);
     if (!gemm(s, l_att_, H, L.o, l_x_, H, R, ACT_NONE, true, l_x_, H, nullptr, &L.post_norm, l_h_))
       norm(s, l_x_, H, L.post_norm, l_h_, H, R, H, c.llm_rms_eps, false, true);
     gemm(s, l_h_, H, L.gu, l_act_, F, R, ACT_NONE, false, nullptr, 0, nullptr, nullptr, nullptr, true);  // silu(g) * u
@@ -1279,12 +1329,12 @@ void Model<T, TS>::llm_decode_step(hipStream_t s, int B, bool keep_q) {
   // More than 4 sequences per call: the FMA GEMV would stream every weight twice (4 batch rows per pass) and
   // its VALU work grows with B, so the linears go through the MFMA GEMM (M = B rows of a 64/128-row tile,
   // split-K to fill the chip: weights are read once) with the norms / SwiGLU as in prefill.
-  const bool mfma_decode = sizeof(T) == 2 && B > 4;
+  const bool mfma_decode = IS16 && B > 4;
   bool h_ready = false;
   for (int i = 0; i < nl; ++i) {
     LlmLayer& L = llm_layers_[i];
-    T* kc = kcache_ + cache_layer_stride_ * i;
-    T* vc = vcache_ + cache_layer_stride_ * i;
+    Q* kc = kcache_ + cache_layer_stride_ * i;
+    Q* vc = vcache_ + cache_layer_stride_ * i;
     if (mfma_decode) {
       if (!h_ready) norm(s, d_x_, H, L.in_norm, l_h_, H, B, H, c.llm_rms_eps, false, true);
       gemm(s, l_h_, H, L.qkv, d_qkv_, 3 * H, B, ACT_NONE, true);
@@ -1294,10 +1344,10 @@ void Model<T, TS>::llm_decode_step(hipStream_t s, int B, bool keep_q) {
       g.ldy = 3 * H; g.B = B; g.N = 3 * H; g.K = H;
       launch_gemv<T>(g, s);
     }
-    T* qk = (keep_q && i == nl - 1) ? q_last_ : nullptr;
-    if (!launch_decode_attn<T>(d_qkv_, B, nh, hd, pos_dev_, rope_tab_, kc, vc, S, 1.f / sqrtf((float)hd), d_att_, qk,
+    Q* qk = (keep_q && i == nl - 1) ? q_last_ : nullptr;
+    if (!launch_decode_attn<Q>(d_qkv_, B, nh, hd, pos_dev_, rope_tab_, kc, vc, S, 1.f / sqrtf((float)hd), d_att_, qk,
                                s)) {
-      launch_rope_cache_f32<T>(d_qkv_, B, nh, hd, pos_dev_, rope_tab_, d_q_, kc, vc, S, qk, s);
+      launch_rope_cache_f32<Q>(d_qkv_, B, nh, hd, pos_dev_, rope_tab_, d_q_, kc, vc, S, qk, s);
       AttnArgs a;
       a.Q = d_q_; a.K = kc; a.V = vc; a.O = d_att_; a.o_f32 = 1;
       a.q_bs = H; a.q_rs = H; a.q_hs = hd;
@@ -1306,10 +1356,10 @@ void Model<T, TS>::llm_decode_step(hipStream_t s, int B, bool keep_q) {
       a.B = B; a.H = nh; a.Sq = 1; a.Sk = S; a.hd = hd;
       a.scale = 1.f / sqrtf((float)hd);
       a.kv_len = kvlen_dev_;
-      launch_attention<T>(a, s);
+      launch_attention<Q>(a, s);
     }
     if (mfma_decode) {
-      launch_convert<T>(d_att_, H, l_att_, H, B, H, s);
+      launch_convert<T>(d_att_, H, l_att_, apad<T>(H), B, H, s);
       if (!gemm(s, l_att_, H, L.o, d_x_, H, B, ACT_NONE, true, d_x_, H, nullptr, &L.post_norm, l_h_))
         norm(s, d_x_, H, L.post_norm, l_h_, H, B, H, c.llm_rms_eps, false, true);
       gemm(s, l_h_, H, L.gu, l_act_, F, B, ACT_NONE, false, nullptr, 0, nullptr, nullptr, nullptr, true);
@@ -1335,7 +1385,7 @@ void Model<T, TS>::llm_decode_step(hipStream_t s, int B, bool keep_q) {
   h.xn_out = hidden_all_; h.xn_row_map = rowmap_dev_; h.xn_ld = H;
   launch_gemv<T>(h, s);
   // argmax, pos += 1, and the next step's embedding row / cache row index / key count
-  launch_argmax_next(l_logits_, B, c.llm_vocab, c.llm_vocab, next_dev_, pos_dev_, emb_table_, sizeof(T) == 2, H, S, d_x_,
+  launch_argmax_next(l_logits_, B, c.llm_vocab, c.llm_vocab, next_dev_, pos_dev_, emb_table_, sizeof(W) == 2, H, S, d_x_,
                      rowmap_dev_, kvlen_dev_, s);
 }
 
@@ -1355,7 +1405,7 @@ void Model<T, TS>::llm_forward(hipStream_t s, const float* embeds, const int32_t
     HIP_TRY(hipMemcpyAsync(hidden + (size_t)b * Sn * H, hidden_all_ + (size_t)b * c.llm_max_seq * H,
                            (size_t)Sn * H * 4, hipMemcpyDeviceToDevice, s));
   if (logits) {
-    launch_convert<T>(hidden, H, l_h_, H, B * Sn, H, s);
+    launch_convert<T>(hidden, H, l_h_, apad<T>(H), B * Sn, H, s);
     gemm(s, l_h_, H, lm_head_, logits, c.llm_vocab, B * Sn, ACT_NONE, true);
   }
   if (attn_q) {
@@ -1364,9 +1414,9 @@ void Model<T, TS>::llm_forward(hipStream_t s, const float* embeds, const int32_t
     for (int b = 0; b < B; ++b) kl[b] = attn_q[b] + 1;
     HIP_TRY(hipMemcpyAsync(kvlen_dev_, kl.data(), B * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(hipStreamSynchronize(s));
-    T* kc = kcache_ + cache_layer_stride_ * (c.llm_layers - 1);
+    Q* kc = kcache_ + cache_layer_stride_ * (c.llm_layers - 1);
     for (int b = 0; b < B; ++b)
-      launch_attn_row_mean<T>(q_last_ + ((size_t)b * S + attn_q[b]) * H, 0, hd, kc + (size_t)b * S * H, 0, H, hd,
+      launch_attn_row_mean<Q>(q_last_ + ((size_t)b * S + attn_q[b]) * H, 0, hd, kc + (size_t)b * S * H, 0, H, hd,
                               kvlen_dev_ + b, 1, nh, hd, 1.f / sqrtf((float)hd), attn_row + (size_t)b * Sn, Sn, s);
   }
 }
@@ -1399,6 +1449,7 @@ void Model<T, TS>::sam_encoder(hipStream_t s, const float* images, int B, float*
     a.q_rs = a.k_rs = a.v_rs = 3 * D; a.o_rs = D;
     a.H = nh; a.hd = hd; a.scale = 1.f / sqrtf((float)hd);
     a.Q = s_qkv_; a.K = s_qkv_ + D; a.V = s_qkv_ + 2 * D; a.O = s_att_;
+    a.o_split = SPS;
     // decomposed rel-pos bias: P = q . [rel_pos_h | rel_pos_w]^T for every head in ONE batched MFMA GEMM
     // (batch = heads, A = the q columns of the fused qkv buffer); the attention kernel applies the shift.
     auto rel_gemm = [&](int rows) {
@@ -1406,16 +1457,16 @@ void Model<T, TS>::sam_encoder(hipStream_t s, const float* images, int B, float*
       r.A = s_qkv_; r.lda = 3 * D; r.sA = hd; r.W = L.rel.w; r.ldw = L.rel.k; r.sW = 0;
       r.C = s_relh_; r.ldc = L.rel.n; r.sC = (int64_t)rows * L.rel.n; r.M = rows; r.N = L.rel.n; r.K = L.rel.k;
       r.c_f32 = 1; r.batch = nh;
-      launch_gemm<TS>(r, s);
+      launch_gemm<QS>(r, s);
       a.rel_p = s_relh_; a.rel_ld = L.rel.n; a.rel_hs = (int64_t)rows * L.rel.n;
     };
     if (L.global) {
       norm<TS>(s, s_x_, D, L.ln1, s_hglob_, D, RT, D, 1e-6f, false);
-      gemm(s, s_hglob_, D, L.qkv, s_qkv_, 3 * D, RT, ACT_NONE, false);
+      gemm(s, s_hglob_, D, L.qkv, s_qkv_, 3 * D, RT, ACT_NONE, QF32S);
       rel_gemm(RT);
       a.q_bs = a.k_bs = a.v_bs = (int64_t)NT * 3 * D; a.o_bs = (int64_t)NT * D;
       a.B = B; a.Sq = NT; a.Sk = NT; a.kh = g; a.kw = g;
-      launch_attention<TS>(a, s);
+      launch_attention<QS>(a, s);
       gemm(s, s_att_, D, L.proj, s_x_, D, RT, ACT_NONE, true, s_x_, D);
     } else {
       const int RW = B * WR, S2 = ws * ws;
@@ -1431,8 +1482,8 @@ void Model<T, TS>::sam_encoder(hipStream_t s, const float* images, int B, float*
         na.fill_N = 3 * D; na.fill_done = &filled;
         launch_norm<TS>(na, s);
       }
-      gemm(s, s_hglob_, D, L.qkv, s_qkv_, 3 * D, RT, ACT_NONE, false, nullptr, 0, tok2win_);
-      if (!filled) launch_fill_rows_bias<TS>(s_qkv_, 3 * D, pad_rows_, n_pad_rows_ * B, L.qkv.b, 3 * D, s);
+      gemm(s, s_hglob_, D, L.qkv, s_qkv_, 3 * D, RT, ACT_NONE, QF32S, nullptr, 0, tok2win_);
+      if (!filled) launch_fill_rows_bias<QS>(s_qkv_, 3 * D, pad_rows_, n_pad_rows_ * B, L.qkv.b, 3 * D, s);
       if (attention_takes_rel_tables((int)sizeof(TS), hd, S2, S2, ws, ws)) {
         // window bias straight from the tables inside the attention kernel (rows 0.. = rel_pos_h, Np.. = rel_pos_w)
         a.rel_tab_h = L.rel.w; a.rel_tab_w = L.rel.w + (size_t)(L.rel.n / 2) * L.rel.k; a.rel_tab_ld = L.rel.k;
@@ -1441,10 +1492,10 @@ void Model<T, TS>::sam_encoder(hipStream_t s, const float* images, int B, float*
       }
       a.q_bs = a.k_bs = a.v_bs = (int64_t)S2 * 3 * D; a.o_bs = (int64_t)S2 * D;
       a.B = B * nW; a.Sq = S2; a.Sk = S2; a.kh = ws; a.kw = ws;
-      launch_attention<TS>(a, s);
+      launch_attention<QS>(a, s);
       // proj over the REAL tokens only, gathered from the window layout by the GEMM's A-row map (the pad rows' outputs
       // were dropped by the epilogue before: 4900 -> 4096 rows per image, as for qkv)
-      if (sizeof(TS) == 2 && D % 64 == 0)
+      if (IS16S && D % 64 == 0)
         gemm(s, s_att_, D, L.proj, s_x_, D, RT, ACT_NONE, true, s_x_, D, nullptr, nullptr, nullptr, false, -1.f, tok2win_);
       else
         gemm(s, s_att_, D, L.proj, s_x_, D, RW, ACT_NONE, true, s_x_, D, win2tok_);
@@ -1456,7 +1507,7 @@ void Model<T, TS>::sam_encoder(hipStream_t s, const float* images, int B, float*
   if (!to_end) return;
   // neck: 1x1 conv -> LN2d -> 3x3 conv -> LN2d (channels-last tokens; fp32 LayerNorm as the
   // reference forces under fp16, image_encoder.py:119-122)
-  launch_convert<TS>(s_x_, D, s_hglob_, D, RT, D, s);
+  launch_convert<TS>(s_x_, D, s_hglob_, apad<TS>(D), RT, D, s);
   gemm(s, s_hglob_, D, neck0_, s_n0_, C, RT, ACT_NONE, true);
   norm<TS>(s, s_n0_, C, neck1_, s_n1_, C, RT, C, 1e-6f, false);
   launch_im2col_3x3<TS>(s_n1_, B, g, C, s_col3_, s);
@@ -1622,7 +1673,7 @@ int Model<T, TS>::splice_inputs(hipStream_t s, const int64_t* input_ids, const i
   if (Sp > c.llm_max_seq) throw std::runtime_error("prompt longer than llm_max_seq");
   HIP_TRY(hipMemcpyAsync(ids_dev_, input_ids, (size_t)B * Lmax * 8, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(lens_dev_, lens, B * 4, hipMemcpyHostToDevice, s));
-  launch_embed_splice(ids_dev_, lens_dev_, B, Lmax, emb_table_, sizeof(T) == 2, c.llm_vocab, img_feat_, n_img, l_x_, Sp,
+  launch_embed_splice(ids_dev_, lens_dev_, B, Lmax, emb_table_, sizeof(W) == 2, c.llm_vocab, img_feat_, n_img, l_x_, Sp,
                       H, slen_dev_, s);
   if (n_extra > 0) {
     if (n_extra > (int)cfg.max_batch * std::max(cfg.max_seg, 64)) throw std::runtime_error("too many extra slots");
@@ -1760,7 +1811,7 @@ void Model<T, TS>::run_tail(hipStream_t s, const float* sam_images, int B, const
     bool kl_used = false;
     // anyref.py:735-755,767-769: the first [SEG] of image i gets + w * sum_j attn_j * hidden_j
     const int nh = c.llm_heads, hd = H / nh;
-    T* kc = kcache_ + cache_layer_stride_ * (c.llm_layers - 1);
+    Q* kc = kcache_ + cache_layer_stride_ * (c.llm_layers - 1);
     std::vector<char> done(B, 0);
     for (int i = 0; i < nseg; ++i) {
       const int b = seg_b[i];
@@ -1775,7 +1826,7 @@ void Model<T, TS>::run_tail(hipStream_t s, const float* sam_images, int B, const
         stage_kl_[b] = e0 + 1;
         HIP_TRY(hipMemcpyAsync(kvlen_dev_ + b, stage_kl_ + b, 4, hipMemcpyHostToDevice, s));
         kl_used = true;
-        launch_attn_row_mean<T>(q_last_ + ((size_t)b * S + e0) * H, 0, hd, kc + (size_t)b * S * H, 0, H, hd,
+        launch_attn_row_mean<Q>(q_last_ + ((size_t)b * S + e0) * H, 0, hd, kc + (size_t)b * S * H, 0, H, hd,
                                 kvlen_dev_ + b, 1, nh, hd, 1.f / sqrtf((float)hd), attn_row_ + (size_t)b * S, S, s);
       }
       launch_rephrase(hidden_all_ + (size_t)b * S * H, H, attn_row_ + (size_t)b * S, s0, e0, c.rephrase_weight,
@@ -1869,7 +1920,7 @@ void Model<T, TS>::generate(hipStream_t s, const float* clip_images, const float
     h.x = l_xlast_; h.ldx = H; gemv_w(h, lm_head_); h.y = l_logits_; h.ldy = c.llm_vocab; h.B = B; h.N = c.llm_vocab;
     h.K = H;
     launch_gemv<T>(h, s);
-    launch_argmax_next(l_logits_, B, c.llm_vocab, c.llm_vocab, next_dev_, pos_dev_, emb_table_, sizeof(T) == 2, H, S, d_x_,
+    launch_argmax_next(l_logits_, B, c.llm_vocab, c.llm_vocab, next_dev_, pos_dev_, emb_table_, sizeof(W) == 2, H, S, d_x_,
                        rowmap_dev_, kvlen_dev_, s);
   }
   // greedy loop (HF greedy search: stop a row at EOS, pad finished rows; anyref.py:704-716)
@@ -1974,7 +2025,7 @@ void Model<T, TS>::forward_teacher(hipStream_t s, const float* clip_images, cons
   if (out_logits) {
     // [B, Sp, vocab] for the caller's LM loss
     for (int b = 0; b < B; ++b) {
-      launch_convert<T>(hidden_all_ + (size_t)b * S * H, H, l_h_, H, slen[b], H, s);
+      launch_convert<T>(hidden_all_ + (size_t)b * S * H, H, l_h_, apad<T>(H), slen[b], H, s);
       gemm(s, l_h_, H, lm_head_, out_logits + (size_t)b * Sp * c.llm_vocab, c.llm_vocab, slen[b], ACT_NONE, true);
     }
   }
@@ -2036,6 +2087,7 @@ void Model<T, TS>::seg_tail(hipStream_t s, const float* sam_images, const int64_
 
 std::unique_ptr<ModelBase> make_model(const anyref_config& cfg, int device) {
   if (cfg.mode == ANYREF_MODE_PARITY) return std::unique_ptr<ModelBase>(new Model<float>(cfg, device));
+  if (cfg.mode == ANYREF_MODE_PARITY16) return std::unique_ptr<ModelBase>(new Model<sp16, sp16>(cfg, device));
   if (cfg.mode == ANYREF_MODE_PERF || cfg.mode == ANYREF_MODE_PERF_FP8W) {
     static const bool sam_bf16 = getenv("ANYREF_SAM_BF16") != nullptr;  // A/B: the all-bf16 handle of rounds 1-2
     if (sam_bf16) return std::unique_ptr<ModelBase>(new Model<bf16, bf16>(cfg, device));

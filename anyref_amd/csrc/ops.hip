@@ -2,6 +2,7 @@
 // layout allows, fp32 math throughout).
 #include <algorithm>
 #include <cstring>
+#include <type_traits>
 
 #include "kernels.h"
 
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(256) void norm_kernel(NormArgs a) {
     if (a.y_f32)
       yf[d] = o;
     else
-      yt[d] = from_f32<T>(o);
+      st1<T>(yt, d, o);
   }
 }
 
@@ -275,10 +276,12 @@ __global__ __launch_bounds__(256) void norm_kernel(NormArgs a) {
 template <typename T, int NV>  // NV float4 per thread: D <= 256*4*NV
 __global__ __launch_bounds__(256) void norm_wide_kernel(NormArgs a) {
   if ((int)blockIdx.x >= a.M) {  // the side job: one bias row per extra workgroup (fill_N % 4 == 0, 8-byte aligned rows)
-    T* d = reinterpret_cast<T*>(a.fill_dst) + (int64_t)a.fill_rows[blockIdx.x - a.M] * a.fill_ld;
+    // (split-pair mode: the q/k/v rows the fill writes feed the attention kernels, which read f32)
+    using FT = std::conditional_t<is_split<T>::value, float, T>;
+    FT* d = reinterpret_cast<FT*>(a.fill_dst) + (int64_t)a.fill_rows[blockIdx.x - a.M] * a.fill_ld;
     for (int n = threadIdx.x * 4; n < a.fill_N; n += 256 * 4) {
       const float4v b = *reinterpret_cast<const float4v*>(a.fill_bias + n);
-      store4_from_f32<T>(d + n, b[0], b[1], b[2], b[3]);
+      store4_from_f32<FT>(d + n, b[0], b[1], b[2], b[3]);
     }
     return;
   }
@@ -342,7 +345,7 @@ __global__ __launch_bounds__(256) void norm_wide_kernel(NormArgs a) {
     if (a.y_f32) {
       *reinterpret_cast<float4v*>(yf + 4 * j) = o;
     } else {
-      store4_from_f32<T>(yt + 4 * j, o[0], o[1], o[2], o[3]);
+      st4<T>(yt, 4 * j, o[0], o[1], o[2], o[3]);
     }
   }
 }
@@ -386,6 +389,7 @@ void launch_norm(const NormArgs& a, hipStream_t s) {
 template void launch_norm<float>(const NormArgs&, hipStream_t);
 template void launch_norm<bf16>(const NormArgs&, hipStream_t);
 template void launch_norm<f16>(const NormArgs&, hipStream_t);
+template void launch_norm<sp16>(const NormArgs&, hipStream_t);
 
 // ---------------------------------------------------------------------------------------------
 // im2col
@@ -406,7 +410,7 @@ __global__ void im2col_patch_kernel(const float* __restrict__ img, int B, int S,
       const int kx = k % p, ky = (k / p) % p, c = k / (p * p);
       v = img[(((int64_t)b * 3 + c) * S + (py * p + ky)) * S + px * p + kx];
     }
-    out[i] = from_f32<T>(v);
+    st1<T>(out + row * Kp, k, v);
   }
 }
 template <typename T>
@@ -420,6 +424,7 @@ void launch_im2col_patch(const float* img, int B, int S, int p, void* out, int K
 template void launch_im2col_patch<float>(const float*, int, int, int, void*, int, hipStream_t);
 template void launch_im2col_patch<bf16>(const float*, int, int, int, void*, int, hipStream_t);
 template void launch_im2col_patch<f16>(const float*, int, int, int, void*, int, hipStream_t);
+template void launch_im2col_patch<sp16>(const float*, int, int, int, void*, int, hipStream_t);
 
 template <typename T>
 __global__ void im2col_3x3_kernel(const T* __restrict__ in, int B, int g, int C, T* __restrict__ out) {
@@ -432,9 +437,17 @@ __global__ void im2col_3x3_kernel(const T* __restrict__ in, int B, int g, int C,
     const int64_t row = i / (9 * (int64_t)C);
     const int x = (int)(row % g), y = (int)((row / g) % g), b = (int)(row / ((int64_t)g * g));
     const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
-    T v = from_f32<T>(0.f);
-    if (yy >= 0 && yy < g && xx >= 0 && xx < g) v = in[(((int64_t)b * g + yy) * g + xx) * C + c];
-    out[i] = v;
+    const bool in_img = yy >= 0 && yy < g && xx >= 0 && xx < g;
+    if constexpr (is_split<T>::value) {  // both terms of the pair travel as they are
+      const uint16_t* ip = reinterpret_cast<const uint16_t*>(in + (((int64_t)b * g + yy) * g + xx) * C) + sp_col(c);
+      uint16_t* op = reinterpret_cast<uint16_t*>(out + row * 9 * C) + sp_col(tap * C + c);
+      op[0] = in_img ? ip[0] : (uint16_t)0;
+      op[64] = in_img ? ip[64] : (uint16_t)0;
+    } else {
+      T v = from_f32<T>(0.f);
+      if (in_img) v = in[(((int64_t)b * g + yy) * g + xx) * C + c];
+      out[i] = v;
+    }
   }
 }
 template <typename T>
@@ -447,6 +460,7 @@ void launch_im2col_3x3(const void* in, int B, int g, int C, void* out, hipStream
 template void launch_im2col_3x3<float>(const void*, int, int, int, void*, hipStream_t);
 template void launch_im2col_3x3<bf16>(const void*, int, int, int, void*, hipStream_t);
 template void launch_im2col_3x3<f16>(const void*, int, int, int, void*, hipStream_t);
+template void launch_im2col_3x3<sp16>(const void*, int, int, int, void*, hipStream_t);
 
 // ---------------------------------------------------------------------------------------------
 // converts / adds
@@ -458,7 +472,7 @@ __global__ void convert_kernel(const float* __restrict__ in, int64_t ld_in, T* _
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
        i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = i / cols, c = i % cols;
-    out[r * ld_out + c] = from_f32<T>(in[r * ld_in + c]);
+    st1<T>(out + r * ld_out, (int)c, in[r * ld_in + c]);
   }
 }
 template <typename T>
@@ -473,6 +487,24 @@ void launch_convert(const float* in, int64_t ld_in, void* out, int64_t ld_out, i
 template void launch_convert<float>(const float*, int64_t, void*, int64_t, int, int, hipStream_t);
 template void launch_convert<bf16>(const float*, int64_t, void*, int64_t, int, int, hipStream_t);
 template void launch_convert<f16>(const float*, int64_t, void*, int64_t, int, int, hipStream_t);
+template void launch_convert<sp16>(const float*, int64_t, void*, int64_t, int, int, hipStream_t);
+
+// split-pair rows back to f32 (tests, and wherever an f32 view of an sp16 matrix is needed): out[r, c] = hi + lo
+__global__ void unsplit_kernel(const sp16* __restrict__ in, int64_t ld_in, float* __restrict__ out, int64_t ld_out,
+                               int rows, int cols) {
+  const int64_t total = (int64_t)rows * cols;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cols, c = i % cols;
+    out[r * ld_out + c] = sp_load(in + r * ld_in, (int)c);
+  }
+}
+void launch_unsplit(const void* in, int64_t ld_in, float* out, int64_t ld_out, int rows, int cols, hipStream_t s) {
+  const int64_t total = (int64_t)rows * cols;
+  if (total <= 0) return;
+  const int grid = (int)(cdiv64(total, 256) < 8192 ? cdiv64(total, 256) : 8192);
+  hipLaunchKernelGGL(unsplit_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<const sp16*>(in), ld_in, out, ld_out, rows,
+                     cols);
+}
 
 template <typename T>
 __global__ void add_rows_kernel(const float* __restrict__ a, const float* __restrict__ b, int bmod,
@@ -554,7 +586,7 @@ __global__ void im2col_conv1_kernel(const float* __restrict__ img, int n, int Hh
     const int e = (int)(i % KK);
     const int64_t row = i / KK;
     const int px = (int)(row % gw), py = (int)((row / gw) % gh), b = (int)(row / ((int64_t)gh * gw));
-    out[i] = from_f32<T>(img[((int64_t)b * Hh + py * st + e / k) * Ww + px * st + e % k]);
+    st1<T>(out + row * KK, e, img[((int64_t)b * Hh + py * st + e / k) * Ww + px * st + e % k]);
   }
 }
 template <typename T>
@@ -567,6 +599,7 @@ void launch_im2col_conv1(const float* img, int n, int Hh, int Ww, int k, int st,
 }
 template void launch_im2col_conv1<float>(const float*, int, int, int, int, int, void*, hipStream_t);
 template void launch_im2col_conv1<bf16>(const float*, int, int, int, int, int, void*, hipStream_t);
+template void launch_im2col_conv1<sp16>(const float*, int, int, int, int, int, void*, hipStream_t);
 
 // f-4: ImageBind audio head tail (imagebind_model.py:425-428): y = x / max(||x||_2, 1e-12) * scale, one block per row
 __global__ __launch_bounds__(256) void l2norm_scale_kernel(const float* __restrict__ x, int D, float scale,

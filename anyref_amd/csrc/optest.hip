@@ -1,5 +1,7 @@
 // Kernel-level C entry points for the parity tests (include/anyref_hip_ops.h).
+#include <algorithm>
 #include <string>
+#include <vector>
 
 #include "../../include/anyref_hip_ops.h"
 #include "kernels.h"
@@ -22,6 +24,17 @@ static thread_local std::string g_op_err;
     return 2;                                            \
   }
 
+namespace {
+// t = 3 (split pairs, ANYREF_MODE_PARITY16): the entry points keep their f32 interface -- an f32 operand that the mode
+// carries as a bf16 pair is split into a temporary here, a pair-typed result is read back as hi + lo
+struct TmpBuf {
+  void* p = nullptr;
+  explicit TmpBuf(size_t bytes) { HIP_TRY(hipMalloc(&p, bytes ? bytes : 16)); HIP_TRY(hipMemset(p, 0, bytes ? bytes : 16)); }
+  ~TmpBuf() { (void)hipDeviceSynchronize(); (void)hipFree(p); }
+};
+inline int pad64(int k) { return (k + 63) / 64 * 64; }
+}  // namespace
+
 extern "C" {
 
 const char* anyref_op_last_error(void) { return g_op_err.c_str(); }
@@ -33,7 +46,28 @@ int anyref_op_gemm(int t, void* stream, const void* A, const void* W, const floa
     a.A = A; a.lda = K; a.W = W; a.ldw = K; a.bias = bias; a.C = C; a.ldc = N; a.resid = resid; a.ldr = N;
     a.row_map = row_map; a.M = M; a.N = N; a.K = K; a.act = act; a.c_f32 = c_f32;
     if (const char* e = getenv("ANYREF_OPTEST_LDW_PAD")) a.ldw = K + atoi(e);  // probe: padded weight rows
-    if (t == 0) launch_gemm<float>(a, (hipStream_t)stream);
+    if (t == 3) {  // A f32 [M,K] -> pairs; W bf16 [N,K] (K % 64 == 0); C f32 [*, N] either way (read back from pairs if !c_f32)
+      hipStream_t st = (hipStream_t)stream;
+      if (K % 64) throw std::runtime_error("op_gemm t=3: K % 64 != 0");
+      TmpBuf As((size_t)M * K * 4);
+      launch_convert<sp16>(reinterpret_cast<const float*>(A), K, As.p, K, M, K, st);
+      a.A = As.p;
+      if (c_f32) {
+        launch_gemm<sp16>(a, st);
+      } else {
+        int rows = M;
+        if (row_map) {
+          std::vector<int> h(M);
+          HIP_TRY(hipMemcpy(h.data(), row_map, M * 4, hipMemcpyDeviceToHost));
+          for (int v : h) rows = std::max(rows, v + 1);
+        }
+        TmpBuf Cs((size_t)rows * pad64(N) * 4);
+        a.C = Cs.p; a.ldc = pad64(N);
+        launch_gemm<sp16>(a, st);
+        launch_unsplit(Cs.p, pad64(N), reinterpret_cast<float*>(C), N, rows, N, st);
+      }
+    }
+    else if (t == 0) launch_gemm<float>(a, (hipStream_t)stream);
     else if (t == 2) launch_gemm<f16>(a, (hipStream_t)stream);
     else launch_gemm<bf16>(a, (hipStream_t)stream);
   });
@@ -46,7 +80,8 @@ int anyref_op_gemv(int t, void* stream, const float* x, const float* gain, float
     a.x = x; a.ldx = K; a.gain = gain; a.eps = eps; a.W = W; a.W2 = W2; a.bias = bias; a.y = y; a.resid = resid;
     a.ldy = N; a.B = B; a.N = N; a.K = K; a.act = act;
     if (const char* e = getenv("ANYREF_OPTEST_LDW_PAD")) a.ldw = K + atoi(e);  // probe: padded weight rows
-    if (t == 0) launch_gemv<float>(a, (hipStream_t)stream); else launch_gemv<bf16>(a, (hipStream_t)stream);
+    if (t == 3) launch_gemv<sp16>(a, (hipStream_t)stream);  // W bf16, x f32 staged as f32
+    else if (t == 0) launch_gemv<float>(a, (hipStream_t)stream); else launch_gemv<bf16>(a, (hipStream_t)stream);
   });
 }
 
@@ -56,6 +91,12 @@ int anyref_op_norm(int t, void* stream, const float* x, const float* gain, const
     NormArgs a;
     a.x = x; a.ldx = D; a.gain = gain; a.bias = bias; a.y = y; a.ldy = D; a.M = M; a.D = D; a.eps = eps;
     a.rms = rms; a.y_f32 = 1;
+    if (t == 3) {  // the norm writes pairs; y gets hi + lo
+      TmpBuf Ys((size_t)M * pad64(D) * 4);
+      a.y = Ys.p; a.ldy = pad64(D); a.y_f32 = 0;
+      launch_norm<sp16>(a, (hipStream_t)stream);
+      launch_unsplit(Ys.p, pad64(D), y, D, M, D, (hipStream_t)stream);
+    } else
     if (t == 0) launch_norm<float>(a, (hipStream_t)stream);
     else if (t == 2) launch_norm<f16>(a, (hipStream_t)stream);
     else launch_norm<bf16>(a, (hipStream_t)stream);
@@ -73,6 +114,13 @@ int anyref_op_attention(int t, void* stream, const void* q, const void* k, const
     a.o_bs = (int64_t)Sq * H * hd; a.o_rs = H * hd; a.o_hs = hd;
     a.B = B; a.H = H; a.Sq = Sq; a.Sk = Sk; a.hd = hd; a.scale = scale; a.causal = causal; a.kv_len = kv_len;
     a.rel_h = rel_h; a.rel_w = rel_w; a.kh = kh; a.kw = kw;
+    if (t == 3) {  // f32 operands, pair-typed output rows [B*Sq, H*hd] (H*hd % 64 == 0); o gets hi + lo
+      if ((H * hd) % 64) throw std::runtime_error("op_attention t=3: H * hd % 64 != 0");
+      TmpBuf Os((size_t)B * Sq * H * hd * 4);
+      a.O = Os.p; a.o_split = 1;
+      launch_attention<float>(a, (hipStream_t)stream);
+      launch_unsplit(Os.p, H * hd, reinterpret_cast<float*>(o), H * hd, B * Sq, H * hd, (hipStream_t)stream);
+    } else
     if (t == 0) launch_attention<float>(a, (hipStream_t)stream);
     else if (t == 2) launch_attention<f16>(a, (hipStream_t)stream);
     else launch_attention<bf16>(a, (hipStream_t)stream);

@@ -89,7 +89,8 @@ class AnyRefForCausalLM:
         self.add_audio_encoder = bool(kwargs.pop("add_audio_encoder", False))
         self.imagebind_ckpt = kwargs.pop("imagebind_ckpt", "model/ImageBind/imagebind_huge.pth")
         self.cfg = cfg
-        self.mode = {"parity": _lib.MODE_PARITY, "perf": _lib.MODE_PERF, "perf_fp8w": _lib.MODE_PERF_FP8W}[mode]
+        self.mode = {"parity": _lib.MODE_PARITY, "perf": _lib.MODE_PERF, "perf_fp8w": _lib.MODE_PERF_FP8W,
+                     "parity16": _lib.MODE_PARITY16}[mode]
         self.mode_name = mode
         self.device_index = device
         self.device = torch.device("cuda", device)

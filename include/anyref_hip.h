@@ -38,6 +38,14 @@ extern "C" {
  * per output row (weight-only, quantised at finalize: scale = max|row| / 448, RNE): half the weight bytes of
  * the HBM-bound decode; activations, the vision towers and SAM stay as in PERF (BASELINE config 5) */
 #define ANYREF_MODE_PERF_FP8W 2
+/* The tolerance-meeting mode at 16-bit MFMA rate (north_star: mask logits within 1e-3, identical greedy ids): weights stay in
+ * their exact bf16 storage (never widened in HBM: a decode step streams the same bytes as PERF); every activation that feeds a
+ * matrix product is f32 carried as a PAIR of bf16 terms (hi = bf16(a), lo = bf16(a - hi): |a - hi - lo| <= 2^-18 |a|), one bf16
+ * MFMA pass per term into the same f32 accumulator; the decode GEMV multiplies the f32 activation row (kept in LDS as f32)
+ * with the bf16 weights; attention operands (q, k, v, the KV cache), residual streams, norms and the mask decoder are f32 as
+ * in PARITY.  Inputs must be weights that are exactly representable in bf16 (the synthetic workloads round once; a real
+ * fp32 SAM checkpoint is rounded to bf16 at finalize, as the reference's own fp16 evaluation rounds it to fp16). */
+#define ANYREF_MODE_PARITY16 3
 
 typedef struct anyref_config {
   int32_t abi_version; /* = ANYREF_ABI_VERSION */

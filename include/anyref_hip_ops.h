@@ -2,7 +2,8 @@
  * anyref_hip_ops.h — kernel-level entry points of libanyref_hip.so used by the parity tests
  * (tests/test_gpu_ops.py) to check every hand-written kernel against the oracle / torch fp32 in
  * isolation.  Not part of the drop-in boundary (that is anyref_hip.h).
- * `t` selects the storage type: 0 = f32 (MFMA 16x16x4 f32), 1 = bf16 (MFMA 16x16x32 bf16), 2 = f16 (MFMA 16x16x32
+ * `t` selects the storage type: 0 = f32 (MFMA 16x16x4 f32), 1 = bf16 (MFMA 16x16x32 bf16), 3 = split pairs (ANYREF_MODE_PARITY16: f32
+ * operands at the interface, carried as two bf16 terms inside; weights bf16; gemm / gemv / norm / attention entries), 2 = f16 (MFMA 16x16x32
  * f16: the SAM image encoder of the perf build; GEMM, norm and attention entries).
  * All pointers are device pointers; `stream` is a hipStream_t.
  */
