@@ -74,7 +74,9 @@ def main():
                          "ImageBind trunk, configs[3]); c5: 13B LLM, fp8 weights, batch 8 (configs[4]); tiny: plumbing")
     ap.add_argument("--audio-trunk", default="hip", choices=["hip", "torch"],
                     help="c4: ImageBind audio trunk inside the HIP handle (f-4) or as the PyTorch-ROCm module")
-    ap.add_argument("--mode", default=None, choices=["perf", "perf_fp8w"], help="default: perf (bf16); c5: perf_fp8w")
+    ap.add_argument("--mode", default=None, choices=["perf", "perf_fp8w", "parity16"],
+                    help="default: perf (bf16 LLaMA / CLIP, f16 SAM encoder); c5: perf_fp8w; parity16: the tolerance-meeting mode "
+                         "(f32 activations as bf16 pairs x exactly stored bf16 weights) as the timed headline")
     ap.add_argument("--batch-per-gpu", type=int, default=None, help="default: 1 (c2 / c4), 4 (c3), 8 (c5)")
     ap.add_argument("--roofline-steps", type=int, default=3, help="steps of the untimed kernel-timestamp passes")
     ap.add_argument("--stamps-out", default=None,
@@ -299,7 +301,7 @@ def main():
         elif dom:
             # a compute-bound dominant kernel (large batches): hipEvent brackets of an eager pass, overlap off
             compute = dom.startswith(("gemm", "attn"))
-            peak = (PEAK_BF16_TFLOPS if "bf16" in dom else PEAK_F32_TFLOPS) if compute else PEAK_HBM_GBS
+            peak = (PEAK_BF16_TFLOPS if any(t in dom for t in ("bf16", "f16", "sp16")) else PEAK_F32_TFLOPS) if compute else PEAK_HBM_GBS
             sel = {k: v for k, v in table.items() if family(k) == dom and v["count"]}
             ms = sum(v["ms"] for v in sel.values())
             work = sum(v["flops"] / 1e12 if compute else v["bytes"] / 1e9 for v in sel.values())
@@ -329,7 +331,10 @@ def main():
                        "tiny": "images/sec (tiny plumbing config)"}[config],
             "value": round(ips, 3), "unit": "images/sec", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16" if mode == "perf" else "bf16 (LLM linear weights fp8 e4m3, weight-only)",
+            "vs_baseline": None,
+            "dtype": {"perf": "bf16 (LLaMA / CLIP) + f16 (SAM encoder)",
+                      "perf_fp8w": "bf16 (LLaMA / CLIP; LLM linear weights fp8 e4m3, weight-only) + f16 (SAM encoder)",
+                      "parity16": "f32 activations as bf16 pairs x bf16 weights (bf16 MFMA, f32 accumulate); f32 attention"}[mode],
             "data": "synthetic",
             "config": {"workload": workload, "batch_per_gpu": B, "global_batch": n_global, "parallelism": f"dp{world}",
                        "max_new_tokens": T, "weights": "random-init N(0,0.02^2) rounded to bf16",
@@ -379,7 +384,7 @@ def main():
         import gc
         for name, conf in (("c3_shape", "c3"), ("c4", "c4"), ("c5", "c5")):
             try:
-                r2, c2 = measure(conf, 5, 2, roofline_steps=1, stamps_out="", full=False)
+                r2, c2 = measure(conf, 5, 2, mode="perf_fp8w" if conf == "c5" else "perf", roofline_steps=1, stamps_out="", full=False)
                 del c2
                 secondary[name] = {k: r2[k] for k in ("metric", "value", "ms_per_step", "dtype", "config", "roofline")}
             except Exception as e:          # a secondary line must never cost the headline
@@ -390,6 +395,38 @@ def main():
                              "(4 images per call) on one GPU; parity of these shapes: tests/test_gpu_e2e.py, test_gpu_audio.py, "
                              "test_gpu_fp8w.py")
         res["secondary"] = secondary
+
+    # ---- the tolerance-meeting mode, timed in the same run on the same workload and launch path (N = 1, C2) ----
+    # north_star's bar (mask logits within 1e-3, identical greedy ids) is met by `parity16`: weights in their exact bf16
+    # storage, every activation that feeds a matrix product carried as a pair of bf16 terms (2^-18 relative), f32
+    # attention operands; its parity numbers (fan-in workload, where the bar bites) are attached below from `parity`
+    tol = None
+    if world == 1 and args.config == "c2" and mode != "parity16" and os.environ.get("ANYREF_BENCH_TOLERANCE", "1") != "0":
+        try:
+            m16 = AnyRefForCausalLM.from_state_dict(cfg, sd, mode="parity16", device=local, max_batch=ctx["B"], max_seg=2)
+            m16.config.eos_token_id = None
+            o16, _, _ = m16.generate(clip, ids, sam, sizes, H, W, max_new_tokens=T)
+            m16.set_seg_token_idx(int(o16[0, ids.shape[1] + 2]))
+            for _ in range(args.warmup):
+                m16.generate(clip, ids, sam, sizes, H, W, max_new_tokens=T)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                m16.generate(clip, ids, sam, sizes, H, W, max_new_tokens=T)
+            barrier()
+            dt16 = (time.perf_counter() - t0) / args.steps
+            tol = {"mode": "parity16", "value": round(ctx["B"] / dt16, 3), "unit": "images/sec", "ms_per_step": round(dt16 * 1e3, 3),
+                   "steps": args.steps, "warmup": args.warmup, "device_gib": round(m16.device_bytes / 2 ** 30, 2),
+                   "arithmetic": "bf16 weights exactly as stored (never widened in HBM); activations f32 carried as two bf16 terms "
+                                 "(hi + lo, 2^-18 relative), one bf16 MFMA pass per term; decode GEMV: f32 activation row x bf16 "
+                                 "weights; attention operands, KV cache, norms, residual streams, mask decoder f32",
+                   "mask_logit_max_abs_err": None, "ids_match_rate": None}
+            del m16
+            torch.cuda.empty_cache()
+        except Exception as e:              # must never cost the headline
+            tol = {"mode": "parity16", "error": repr(e)}
+        res["tolerance_mode"] = tol
+        log("[bench] tolerance mode: " + json.dumps(tol))
 
     # ---------------- CPU baseline + parity against it (rank 0, N=1 only) ----------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -459,6 +496,12 @@ def main():
             parity["workload_normal"]["parity"]["ms_per_image"] = round((time.perf_counter() - t1) * 1e3, 2)
             del pm
             torch.cuda.empty_cache()
+            pm = mode_model(sd, cfg, "parity16")
+            t1 = time.perf_counter()
+            parity["workload_normal"]["parity16"] = summarize([compare_generate(pm, ref, *one, T, lm, n_img)])
+            parity["workload_normal"]["parity16"]["ms_per_image"] = round((time.perf_counter() - t1) * 1e3, 2)
+            del pm
+            torch.cuda.empty_cache()
         parity["workload_normal"]["note"] = ("the timed workload (SURVEY.md §8d, every matrix N(0,0.02^2)): logits are nearly "
                                              "flat, so read the errors relative to logit_range")
         # ---- the PARITY workload: fan-in-scaled weights (O(1) activations, peaked LM logits, mask logits of several
@@ -486,7 +529,7 @@ def main():
             log(f"[bench] parity workload: CPU oracle on {n_prompts} prompts (1 with masks) in {time.time() - t0:.0f}s")
             lm2 = sd2_cpu["lm_head.weight"]
             parity["workload_fan_in"] = {}
-            for mode_ in ("parity", "perf"):
+            for mode_ in ("parity", "parity16", "perf"):
                 m2 = mode_model(sd2, cfg, mode_)
                 rows = [compare_generate(m2, refs[i], clip[:1], prompts[i], sam[:1], sizes[:1], H[:1], W[:1], T, lm2, n_img)
                         for i in range(n_prompts)]
@@ -498,12 +541,17 @@ def main():
         # the headline parity numbers (north_star: identical greedy ids, mask logits within 1e-3) per arithmetic mode,
         # taken from the workload where they bite
         src = parity.get("workload_fan_in", parity["workload_normal"])
-        for mode_ in ("parity", "perf"):
+        for mode_ in ("parity", "parity16", "perf"):
             if mode_ in src:
                 parity[mode_] = {k: src[mode_][k] for k in ("ids_match_rate", "mask_logit_max_abs_err", "mask_logit_rel_err",
                                                              "logit_range", "first_divergence_new_token") if k in src[mode_]}
                 parity[mode_]["rel_err"] = src[mode_].get("mask_logit_rel_err")
         res["parity"] = parity
+        if tol and "error" not in tol and "parity16" in parity:
+            tol["mask_logit_max_abs_err"] = parity["parity16"].get("mask_logit_max_abs_err")
+            tol["ids_match_rate"] = parity["parity16"].get("ids_match_rate")
+            tol["logit_range"] = parity["parity16"].get("logit_range")
+            tol["parity_workload"] = "fan_in" if "workload_fan_in" in parity else "normal"
     if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1:
