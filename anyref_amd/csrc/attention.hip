@@ -959,12 +959,8 @@ static void attn_launch_cfg(const AttnArgs& a_in, hipStream_t s) {
     lds += sizeof(T) * 2 * 32 * LDK;
   }
   if (lds > 160 * 1024) throw std::runtime_error("attention: LDS budget exceeded");
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<T, HD, NWV, BKVP, NRES>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr = true;
-  }
+  static KernelAttrOnce once;
+  ensure_dyn_lds(once, reinterpret_cast<const void*>(&attn_kernel<T, HD, NWV, BKVP, NRES>), 160 * 1024);
   // few query blocks over many keys: split the keys until ~256 workgroups (at least 256 keys per split)
   a.kv_splits = 1;
   const int64_t wgs = (int64_t)cdiv(a.Sq, BQ) * a.H * a.B;
@@ -1010,11 +1006,8 @@ static void attn_launch_cfg(const AttnArgs& a_in, hipStream_t s) {
         return;
       } else {
         auto kw = &attn_walk_kernel<T, HD, NWV, BKVP, NRES>;
-        static bool attrw = false;
-        if (!attrw) {
-          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kw), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-          attrw = true;
-        }
+        static KernelAttrOnce oncew;
+        ensure_dyn_lds(oncew, reinterpret_cast<const void*>(kw), 160 * 1024);
         hipLaunchKernelGGL(kw, dim3(a.max_wg), dim3(NWV * 64), lds, s, a, (int)grid.x, (int)grid.y, total);
         return;
       }
@@ -1032,11 +1025,8 @@ static void attn_g2_launch(const AttnArgs& a, hipStream_t s) {
   constexpr int BQ = 32 * NWV, LDK = 96 + 8, LDV = ((HD * 2 + 255) / 256 * 256 + 32) / 2;
   const size_t lds = sizeof(T) * 64 * (LDK + LDV) + sizeof(float) * BQ * (a.kh + 1);
   auto kern = &attn_g2_kernel<T, HD, NWV>;
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr = true;
-  }
+  static KernelAttrOnce once;
+  ensure_dyn_lds(once, reinterpret_cast<const void*>(kern), 160 * 1024);
   const int gx = a.Sq / BQ, gy = a.H, total = gx * gy * a.B;
   static const std::string tag = std::string(is_half16<T>::value ? "attn_f16_hd" : "attn_bf16_hd") + std::to_string(HD) + "_g2w" +
                                  std::to_string(NWV);

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include <stdio.h>
 #include <stdexcept>
 
@@ -322,6 +323,37 @@ __device__ inline float wave_max(float v) {
       throw std::runtime_error(_b);                                                     \
     }                                                                                   \
   } while (0)
+
+// ---- per-device launcher state ---------------------------------------------------------------
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per DEVICE, and launchers are entered from any thread: a host that
+// keeps one handle per GPU in ONE process (or two handles on one GPU from two threads) must not find the attribute "already
+// set" because another device's first launch set a process-wide flag.  One bit per device ordinal per call site; two
+// threads racing on the first launch both set the (idempotent) attribute.
+struct KernelAttrOnce {
+  std::atomic<uint64_t> done[4] = {};  // 256 device ordinals
+};
+inline void ensure_dyn_lds(KernelAttrOnce& st, const void* kernel, int bytes) {
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  std::atomic<uint64_t>& word = st.done[(dev >> 6) & 3];
+  const uint64_t bit = 1ull << (dev & 63);
+  if (word.load(std::memory_order_acquire) & bit) return;
+  HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  word.fetch_or(bit, std::memory_order_release);
+}
+// CU count of the calling thread's current device (cached per device ordinal)
+inline int device_cus() {
+  static std::atomic<int> cache[256] = {};
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  std::atomic<int>& c = cache[dev & 255];
+  int v = c.load(std::memory_order_relaxed);
+  if (!v) {
+    HIP_TRY(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
+    c.store(v, std::memory_order_relaxed);
+  }
+  return v;
+}
 
 __host__ __device__ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

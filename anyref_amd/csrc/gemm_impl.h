@@ -995,12 +995,8 @@ void launch_gemm(const GemmArgs& a_in, hipStream_t s) {
         if constexpr (BN % (WM * WN * 16) == 0 && !is_half16<T>::value && !SP) {
           if (a.w_fp8) {  // fp8 weight operand (LDS of the full-width kernel is an upper bound)
             auto kern8 = &gemm_glds_kernel<BM, BN, WM, WN, NS, true>;
-            static bool attr8 = false;
-            if (!attr8) {
-              HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern8),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-              attr8 = true;
-            }
+            static KernelAttrOnce once8;
+            ensure_dyn_lds(once8, reinterpret_cast<const void*>(kern8), (int)lds);
             const int tiles_m8 = cdiv(a.M, BM), nwg8 = tiles_m8 * cdiv(a.N, BN);
             int gm8 = (int)lround(sqrt((double)(nwg8 > 8 ? nwg8 / 8 : 1)));
             a.group_m = gm8 < 1 ? 1 : (gm8 > tiles_m8 ? tiles_m8 : gm8);
@@ -1013,12 +1009,8 @@ void launch_gemm(const GemmArgs& a_in, hipStream_t s) {
           }
         }
         auto kern = &gemm_glds_kernel<BM, BN, WM, WN, NS, false, false, T>;
-        static bool attr = false;
-        if (!attr) {
-          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)lds));
-          attr = true;
-        }
+        static KernelAttrOnce once;  // (per instantiation of this generic lambda, per device)
+        ensure_dyn_lds(once, reinterpret_cast<const void*>(kern), (int)lds);
         {  // rows per group ~ sqrt(tiles one XCD gets), so its chunk is a near-square rectangle
           const int tiles_m = cdiv(a.M, BM), nwg = tiles_m * cdiv(a.N, BN);
           int gm = (int)lround(sqrt((double)(nwg > 8 ? nwg / 8 : 1)));
@@ -1058,12 +1050,8 @@ void launch_gemm(const GemmArgs& a_in, hipStream_t s) {
               return;
             } else {
               auto kp = &gemm_glds_kernel<BM, BN, WM, WN, NS, false, true, T>;
-              static bool attrp = false;
-              if (!attrp) {
-                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kp), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            (int)lds));
-                attrp = true;
-              }
+              static KernelAttrOnce oncep;
+              ensure_dyn_lds(oncep, reinterpret_cast<const void*>(kp), (int)lds);
               hipLaunchKernelGGL(kp, dim3(cap), dim3(WM * WN * 64), lds, s, a);
               return;
             }
@@ -1078,12 +1066,7 @@ void launch_gemm(const GemmArgs& a_in, hipStream_t s) {
       using I64 = std::integral_constant<int, 64>;
       using I128 = std::integral_constant<int, 128>;
       using I256 = std::integral_constant<int, 256>;
-      static int cus = 0;
-      if (!cus) {
-        int dev = 0;
-        HIP_TRY(hipGetDevice(&dev));
-        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-      }
+      const int cus = device_cus();
       const int64_t t256 = (int64_t)cdiv(a.M, 256) * cdiv(a.N, 256) * a.batch;
       const double fill256 = (double)t256 / (double)(cdiv64(t256, cus) * cus);
       const int64_t t64w = (int64_t)cdiv(a.M, 64) * cdiv(a.N, 256) * a.batch;

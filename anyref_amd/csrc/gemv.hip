@@ -361,11 +361,8 @@ static void gemv_dispatch(const GemvArgs& a_in, int b0, int nb, hipStream_t s) {
     auto launch = [&](auto dual_t, auto w8_t, auto pair_t) {
       constexpr bool DUAL = decltype(dual_t)::value, W8 = decltype(w8_t)::value, PAIR = decltype(pair_t)::value;
       auto kern = &gemv_kernel<T, NB, DUAL, XPT, W8, PAIR>;
-      static bool attr_set = false;  // per instantiation
-      if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        attr_set = true;
-      }
+      static KernelAttrOnce once;  // per instantiation, per device
+      ensure_dyn_lds(once, reinterpret_cast<const void*>(kern), 150 * 1024);
       hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, a, b0, nb);
     };
     using TT = std::true_type;
@@ -433,12 +430,8 @@ void launch_gemv_skinny_f32(const GemvArgs& a, hipStream_t s) {
   auto go = [&](auto nb_tag) {
     constexpr int NB = decltype(nb_tag)::value;
     auto kern = &gemv_kernel<float, NB, false, 8, false, true>;
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                150 * 1024);
-      attr_set = true;
-    }
+    static KernelAttrOnce once;
+    ensure_dyn_lds(once, reinterpret_cast<const void*>(kern), 150 * 1024);
     ProfScope prof("gemv_f32_skinny", 2.0 * a.B * a.N * (double)a.K, (double)a.N * a.K * 4 + (double)a.B * (a.K + a.N) * 4,
                    s);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), (size_t)NB * a.K * sizeof(float), s, a, 0, a.B);

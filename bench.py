@@ -197,6 +197,39 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
         ips = n_global * steps / dt
+        # ---- N > 1: who took part, and what the per-step exchange costs (untimed, after the timed region) ----
+        ranks_info = collective = None
+        if world > 1:
+            # every rank reports the GPU it ran on: the first SCALE record shows N ranks on N DISTINCT devices
+            pr = torch.cuda.get_device_properties(dev)
+            me = {"rank": rank, "local_rank": local, "device_index": dev.index, "device_name": pr.name,
+                  "device_uuid": str(getattr(pr, "uuid", "")), "pci_bus": f"{getattr(pr, 'pci_domain_id', 0):04x}:"
+                  f"{getattr(pr, 'pci_bus_id', 0):02x}:{getattr(pr, 'pci_device_id', 0):02x}", "pid": os.getpid()}
+            ranks_info = [None] * world
+            dist.all_gather_object(ranks_info, me)
+            # the step's exchange alone: the two all-gathers of gather_results on this rank's real result shapes
+            (o_, _, _), ex_ = model.generate(clip, ids, sam, sizes, H, W, max_new_tokens=T, _return_extras="low", **gen_kw)
+            idp_ = torch.zeros(B, Lout, dtype=torch.long, device=dev)
+            idp_[:, : o_.shape[1]] = o_
+            low_, nseg_, len_ = ex_["low_res"], ex_["nseg"].to(dev), ex_["out_lens"].to(dev)
+            for _ in range(2):
+                gather_results(low_, nseg_, idp_, len_, n_global)
+            barrier()
+            t0 = time.perf_counter()
+            n_coll = 10
+            for _ in range(n_coll):
+                gather_results(low_, nseg_, idp_, len_, n_global)
+            barrier()
+            ct = torch.tensor([(time.perf_counter() - t0) / n_coll], dtype=torch.float64,
+                              device=dev if args.dist_backend == "nccl" else "cpu")
+            dist.all_reduce(ct, op=dist.ReduceOp.MAX)
+            bytes_rank = low_.numel() * 4 + B * (Lout + 2) * 8
+            collective = {"backend": "rccl (torch.distributed nccl)" if args.dist_backend == "nccl" else args.dist_backend,
+                          "what": "all_gather_into_tensor of the low-res mask logits [B, max_seg, 256, 256] f32 + one int64 record "
+                                  "per image (ids, [SEG] count, length); full-res masks are re-created per rank",
+                          "bytes_per_rank": int(bytes_rank), "bytes_gathered_per_rank": int(bytes_rank * world),
+                          "ms": round(float(ct.item()) * 1e3, 4), "share_of_step": round(float(ct.item()) / (dt / steps), 5),
+                          "timed": f"{n_coll} exchanges after 2 warm-ups, max over ranks, outside the timed region"}
 
         # ---- untimed: per-kernel table of one step (hipEvent brackets, eager launches) -> the dominant kernel.
         # Tags are per kernel INSTANTIATION (what rocprofv3 lists); the dominant kernel is the kernel template whose
@@ -341,6 +374,10 @@ def main():
                        "launch_path": "hipGraph decode step, SAM encoder on a second stream, profiler off"},
             "roofline": roofline,
         }
+        if ranks_info is not None:
+            res["ranks"] = ranks_info
+            res["distinct_devices"] = len({(r["device_uuid"], r["pci_bus"]) for r in ranks_info})
+            res["collective"] = collective
         if full:
             res["kernel_breakdown"] = breakdown
         if config == "c2" and T == 10 and mode == "perf" and ids.shape[1] == 65:

@@ -101,6 +101,10 @@ def test_bench_two_ranks_same_device_smoke():
     res = json.loads(line)
     assert res["n_gpus"] == 2 and res["steps"] == 2 and res["scaling"] == "weak" and res["value"] > 0
     assert res["config"]["global_batch"] == 2 * res["config"]["batch_per_gpu"]
+    # who took part and what the per-step exchange cost (the first real SCALE record must show N ranks on N devices)
+    assert [r["rank"] for r in res["ranks"]] == [0, 1] and all(r["device_uuid"] or r["pci_bus"] for r in res["ranks"])
+    assert res["distinct_devices"] == 1               # (this rehearsal puts both ranks on cuda:0)
+    assert res["collective"]["ms"] > 0 and res["collective"]["bytes_per_rank"] > 0 and res["collective"]["backend"] == "gloo"
 
 
 _RCCL_WORKER = r'''

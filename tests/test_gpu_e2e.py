@@ -516,3 +516,54 @@ def test_handle_destroyed_on_another_thread_releases_its_workspaces():
     m2 = AnyRefForCausalLM.from_state_dict(cfg, sd, mode="perf", max_batch=1, max_seg=4)
     m2.config.eos_token_id = None
     assert torch.equal(m2.generate(clip, ids_p, sam, sizes, H, W, max_new_tokens=4)[0].cpu(), box["out"])
+
+
+@pytest.mark.parametrize("mode", ["perf", "parity16"])
+def test_two_handles_on_one_device_from_two_threads(mode):
+    """Launcher state (the dynamic-LDS limits set with hipFuncSetAttribute, the CU count behind the tile choice) is kept
+    per device and may be entered from any thread: two handles created on two threads, each running `generate` on its
+    own stream at the same time (first launches included -- that is when the attributes are set and the decode step is
+    captured), give what one handle gives alone, bit for bit."""
+    import threading
+    from anyref_amd.model import AnyRefForCausalLM
+    cfg = config_tiny()
+    sd = {k: v.cuda() for k, v in synth_state_dict(cfg, seed=81, scale=0.05).items()}
+    clip, sam, ids = make_inputs(cfg, 1, seed=82, L=16)
+    ids_p, _ = pad(ids)
+    sizes, H, W = [(224, 224)], [224], [224]
+    ref = AnyRefForCausalLM.from_state_dict(cfg, sd, mode=mode, max_batch=1, max_seg=4)
+    ref.config.eos_token_id = None
+    o0, _, _ = ref.generate(clip, ids_p, sam, sizes, H, W, max_new_tokens=5)
+    seg = int(o0[0, ids_p.shape[1] + 2])
+    ref.set_seg_token_idx(seg)
+    want_ids, want_masks, _ = ref.generate(clip, ids_p, sam, sizes, H, W, max_new_tokens=8)
+    want_ids, want_masks = want_ids.cpu(), [t.cpu() for t in want_masks]
+    torch.cuda.synchronize()
+    box, start = {}, threading.Barrier(2)
+
+    def worker(i):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                start.wait()
+                m = AnyRefForCausalLM.from_state_dict(cfg, sd, mode=mode, max_batch=1, max_seg=4)
+                m.config.eos_token_id = None
+                m.set_seg_token_idx(seg)
+                outs = []
+                for _ in range(4):
+                    o, masks, _ = m.generate(clip, ids_p, sam, sizes, H, W, max_new_tokens=8)
+                    torch.cuda.current_stream().synchronize()
+                    outs.append((o.cpu(), [t.cpu() for t in masks]))
+                box[i] = outs
+        except Exception as e:       # surfaced by the assert below
+            box[i] = e
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for i in range(2):
+        assert not isinstance(box.get(i), Exception), box.get(i)
+        for o, masks in box[i]:
+            assert torch.equal(o, want_ids), f"thread {i}: ids differ"
+            assert len(masks) == len(want_masks) and all(torch.equal(a, b) for a, b in zip(masks, want_masks)), f"thread {i}: masks differ"
