@@ -855,6 +855,308 @@ __global__ __launch_bounds__(NWV * 64, 2) void attn_g2_kernel(AttnArgs a, int gx
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Split-pair attention (ANYREF_MODE_PARITY16): q, k, v are f32 in memory; on their way into registers / LDS every
+// value is split into two bf16 terms (hi = bf16(x), lo = bf16(x - hi), 2^-18 relative) and both products run on the
+// 16-bit MFMA as THREE passes each into the same f32 accumulator --
+//     S^T = Kh Qh^T + Kh Ql^T + Kl Qh^T          O^T += Vh^T Ph^T + Vl^T Ph^T + Vh^T Pl^T
+// (the lo x lo terms are 2^-18 of the result: below the pair's own rounding) -- instead of v_mfma_f32_16x16x4_f32 at 1/16
+// of the rate: 3/16 of the f32 kernel's MFMA time at the same f32-level result.  Same transposed formulation as attn_body
+// (lane = query, P stays in registers, V^T via ds_read_b64_tr_b16), streaming K / V tiles, log2-domain softmax with lazy
+// rescaling; causal / kv_len / q_len masks, rel-pos bias from the P buffer (rel_p) or the rel_h / rel_w arrays; the output
+// rows leave as f32 or as a split pair (o_split: the A operand of the proj / o_proj GEMM).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void split8(const float (&f)[8], short8& hi, short8& lo) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const bf16 h = f2bf(f[i]);
+    hi[i] = (short)h.x;
+    lo[i] = (short)f2bf(f[i] - bf2f(h)).x;
+  }
+}
+template <int HD, int NWV, int BKV>
+__device__ __forceinline__ void attn_sp_body(const AttnArgs& a, const int bx, const int by, const int bz, char* smem) {
+  constexpr int NT = NWV * 64, KS = 32, VEC = 8;
+  constexpr int BQ = 16 * NWV, HDK = (HD + KS - 1) / KS * KS, LDK = HDK + VEC;
+  constexpr int LDV = ((HD * 2 + 255) / 256 * 256 + 32) / 2;
+  constexpr int NB = BKV / 16, DB = HD / 16;
+  static_assert(HD % 16 == 0 && BKV % 16 == 0, "head dim / key tile must be multiples of 16");
+  bf16* Kh = reinterpret_cast<bf16*>(smem);
+  bf16* Kl = Kh + BKV * LDK;
+  bf16* Vh = Kl + BKV * LDK;
+  bf16* Vl = Vh + BKV * LDV;
+  float* relh_s = reinterpret_cast<float*>(Vl + BKV * LDV);
+  float* relw_s = relh_s + BQ * a.kh;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int qi = lane & 15, g = lane >> 4;
+  const int b = bz, h = by, q0 = bx * BQ;
+  const int kv_len = a.kv_len ? a.kv_len[b] : a.Sk;
+  const int q_len = a.q_len ? a.q_len[b] : a.Sq;
+  if (q0 >= q_len) return;  // uniform per workgroup
+  const int pos0 = a.q_pos0 ? a.q_pos0[b] : 0;
+  int kv_end = kv_len;
+  if (a.causal) {
+    const int imax = (q0 + BQ < q_len ? q0 + BQ : q_len) - 1;
+    if (pos0 + imax + 1 < kv_end) kv_end = pos0 + imax + 1;
+  }
+  const float* Qb = reinterpret_cast<const float*>(a.Q) + (int64_t)b * a.q_bs + (int64_t)h * a.q_hs;
+  const float* Kb = reinterpret_cast<const float*>(a.K) + (int64_t)b * a.k_bs + (int64_t)h * a.k_hs;
+  const float* Vb = reinterpret_cast<const float*>(a.V) + (int64_t)b * a.v_bs + (int64_t)h * a.v_hs;
+
+  const int il = wave * 16 + qi, iq = q0 + il;
+  const bool q_ok = iq < q_len;
+  short8 qh[HDK / KS], ql[HDK / KS];
+  {
+    const float* qrow = Qb + (int64_t)(q_ok ? iq : 0) * a.q_rs;
+#pragma unroll
+    for (int kk = 0; kk < HDK / KS; ++kk) {
+      const int d = kk * KS + 8 * g;
+      float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (q_ok && d < HD) {
+        const float4v x0 = *reinterpret_cast<const float4v*>(qrow + d), x1 = *reinterpret_cast<const float4v*>(qrow + d + 4);
+        f[0] = x0[0]; f[1] = x0[1]; f[2] = x0[2]; f[3] = x0[3]; f[4] = x1[0]; f[5] = x1[1]; f[6] = x1[2]; f[7] = x1[3];
+      }
+      split8(f, qh[kk], ql[kk]);
+    }
+  }
+  constexpr float LOG2E = 1.4426950408889634f;
+  const bool has_rel = a.rel_h != nullptr || a.rel_p != nullptr;
+  if (a.rel_p) {
+    const float* P = a.rel_p + (int64_t)h * a.rel_hs + ((int64_t)b * a.Sq + q0) * a.rel_ld;
+    const int np = a.rel_ld / 2;
+    for (int i = tid; i < BQ * a.kh; i += NT) {
+      const int r = i / a.kh, c = i % a.kh;
+      const int y = (q0 + r) / a.kw;
+      relh_s[i] = q0 + r < q_len ? P[(int64_t)r * a.rel_ld + (y - c + a.kh - 1)] * LOG2E : 0.f;
+    }
+    for (int i = tid; i < BQ * a.kw; i += NT) {
+      const int r = i / a.kw, c = i % a.kw;
+      const int x = (q0 + r) % a.kw;
+      relw_s[i] = q0 + r < q_len ? P[(int64_t)r * a.rel_ld + np + (x - c + a.kw - 1)] * LOG2E : 0.f;
+    }
+  } else if (has_rel) {
+    const float* rh = a.rel_h + ((int64_t)b * a.H + h) * a.Sq * a.kh;
+    const float* rw = a.rel_w + ((int64_t)b * a.H + h) * a.Sq * a.kw;
+    for (int i = tid; i < BQ * a.kh; i += NT) {
+      const int r = i / a.kh, c = i % a.kh;
+      relh_s[i] = q0 + r < q_len ? rh[(int64_t)(q0 + r) * a.kh + c] * LOG2E : 0.f;
+    }
+    for (int i = tid; i < BQ * a.kw; i += NT) {
+      const int r = i / a.kw, c = i % a.kw;
+      relw_s[i] = q0 + r < q_len ? rw[(int64_t)(q0 + r) * a.kw + c] * LOG2E : 0.f;
+    }
+  }
+  // key tile = exactly one bias row (SAM global attention: kw == BKV): the kw term of this lane's keys never changes
+  const bool rel_fast = has_rel && a.kw == BKV;
+  const unsigned kw_magic = has_rel ? (1u << 20) / (unsigned)a.kw + 1u : 0u;  // j / kw for j < 4096, kw <= 64
+  float relw_reg[NB][4];
+  if (rel_fast) {
+    __syncthreads();
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) relw_reg[nb][r] = relw_s[il * a.kw + nb * 16 + 4 * g + r];
+  }
+
+  float m_run = -INFINITY, l_run = 0.f;
+  float4v ot[DB];
+#pragma unroll
+  for (int d = 0; d < DB; ++d) ot[d] = float4v{0.f, 0.f, 0.f, 0.f};
+
+  // K [BKV][HDK] and V [BKV][HD] tiles in units of 8 elements (two 16-byte f32 loads -> one 16-byte hi + one 16-byte lo LDS
+  // store); register-staged one tile ahead
+  constexpr int KVEC = HDK / VEC, VVEC = HD / VEC;
+  constexpr int KPT = (BKV * KVEC + NT - 1) / NT, VPT = (BKV * VVEC + NT - 1) / NT;
+  float4v kreg[KPT][2], vreg[VPT][2];
+  auto gload_tile = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+      const int v = tid + i * NT, row = v / KVEC, d = (v % KVEC) * VEC;
+      const bool ok = v < BKV * KVEC && kt + row < kv_end && d < HD;
+      const float* p = Kb + (int64_t)(kt + row) * a.k_rs + d;
+      kreg[i][0] = ok ? *reinterpret_cast<const float4v*>(p) : float4v{0.f, 0.f, 0.f, 0.f};
+      kreg[i][1] = ok ? *reinterpret_cast<const float4v*>(p + 4) : float4v{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+      const int v = tid + i * NT, row = v / VVEC, d = (v % VVEC) * VEC;
+      const bool ok = v < BKV * VVEC && kt + row < kv_end;
+      const float* p = Vb + (int64_t)(kt + row) * a.v_rs + d;
+      vreg[i][0] = ok ? *reinterpret_cast<const float4v*>(p) : float4v{0.f, 0.f, 0.f, 0.f};
+      vreg[i][1] = ok ? *reinterpret_cast<const float4v*>(p + 4) : float4v{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto sstore_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+      const int v = tid + i * NT, row = v / KVEC, d = (v % KVEC) * VEC;
+      if (v < BKV * KVEC) {
+        const float f[8] = {kreg[i][0][0], kreg[i][0][1], kreg[i][0][2], kreg[i][0][3], kreg[i][1][0], kreg[i][1][1], kreg[i][1][2], kreg[i][1][3]};
+        short8 hi, lo;
+        split8(f, hi, lo);
+        *reinterpret_cast<short8*>(&Kh[row * LDK + d]) = hi;
+        *reinterpret_cast<short8*>(&Kl[row * LDK + d]) = lo;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+      const int v = tid + i * NT, row = v / VVEC, d = (v % VVEC) * VEC;
+      if (v < BKV * VVEC) {
+        const float f[8] = {vreg[i][0][0], vreg[i][0][1], vreg[i][0][2], vreg[i][0][3], vreg[i][1][0], vreg[i][1][1], vreg[i][1][2], vreg[i][1][3]};
+        short8 hi, lo;
+        split8(f, hi, lo);
+        *reinterpret_cast<short8*>(&Vh[row * LDV + d]) = hi;
+        *reinterpret_cast<short8*>(&Vl[row * LDV + d]) = lo;
+      }
+    }
+  };
+  if (kv_end > 0) gload_tile(0);
+  const float c1 = a.scale * LOG2E;
+  const uint32_t voff = (uint32_t)((4 * g + (qi >> 2)) * LDV + 4 * (qi & 3)) * 2u;
+  const uint32_t vbase_h = (uint32_t)(reinterpret_cast<const char*>(Vh) - smem) + voff;
+  const uint32_t vbase_l = (uint32_t)(reinterpret_cast<const char*>(Vl) - smem) + voff;
+  for (int kt = 0; kt < kv_end; kt += BKV) {
+    sstore_tile();
+    __syncthreads();
+    if (kt + BKV < kv_end) gload_tile(kt + BKV);
+    const bool active = q0 + wave * 16 < q_len && !(a.causal && kt > pos0 + q0 + wave * 16 + 15);
+    if (active) {
+      // ---- S^T = Kh Qh^T + Kh Ql^T + Kl Qh^T ----
+      float4v st[NB];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        st[nb] = float4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < HDK / KS; ++kk) {
+          const short8 kfh = *reinterpret_cast<const short8*>(&Kh[(nb * 16 + qi) * LDK + kk * KS + 8 * g]);
+          const short8 kfl = *reinterpret_cast<const short8*>(&Kl[(nb * 16 + qi) * LDK + kk * KS + 8 * g]);
+          st[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfl, qh[kk], st[nb], 0, 0, 0);  // small terms first
+          st[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfh, ql[kk], st[nb], 0, 0, 0);
+          st[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfh, qh[kk], st[nb], 0, 0, 0);
+        }
+      }
+      // ---- scale, bias, mask; column softmax of this lane's query (log2 domain) ----
+      float sv[NB][4];
+      float mx = -INFINITY;
+      const float relh_tile = rel_fast ? relh_s[il * a.kh + kt / BKV] : 0.f;
+      const bool need_mask = kt + BKV > kv_len || (a.causal && kt + BKV - 1 > pos0 + q0 + wave * 16);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int j = kt + nb * 16 + 4 * g + r;
+          float sc = st[nb][r] * c1;
+          if (rel_fast) {
+            sc += relh_tile + relw_reg[nb][r];
+          } else if (has_rel) {
+            int jh = (int)(((unsigned)j * kw_magic) >> 20), jw = j - jh * a.kw;
+            if (jh >= a.kh) jh = 0, jw = 0;  // keys past the end (masked below): keep the LDS reads in range
+            sc += relh_s[il * a.kh + jh] + relw_s[il * a.kw + jw];
+          }
+          if (need_mask) {
+            const bool valid = j < kv_len && (!a.causal || j <= pos0 + iq);
+            sc = valid ? sc : -INFINITY;
+          }
+          sv[nb][r] = sc;
+          mx = fmaxf(mx, sc);
+        }
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = mx > m_run + 8.f ? mx : m_run;  // lazy rescaling (attn_body)
+      const bool moved = m_new != m_run;
+      const float mref = m_new == -INFINITY ? 0.f : m_new;
+      if (__builtin_amdgcn_ballot_w64(moved) != 0) {
+        const float alpha = __builtin_amdgcn_exp2f(m_run - mref);
+        l_run *= alpha;
+#pragma unroll
+        for (int d = 0; d < DB; ++d) ot[d] *= alpha;
+        m_run = m_new;
+      }
+      float rs = 0.f;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          sv[nb][r] = __builtin_amdgcn_exp2f(sv[nb][r] - mref);
+          rs += sv[nb][r];
+        }
+      l_run += rs;
+      // ---- O^T += Vh^T Ph^T + Vl^T Ph^T + Vh^T Pl^T ----
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        uint2v vth[DB], vtl[DB];
+        lds_tr_blocks<DB>(vbase_h + (uint32_t)(nb * 16 * LDV * 2), vth);
+        lds_tr_blocks<DB>(vbase_l + (uint32_t)(nb * 16 * LDV * 2), vtl);
+        __builtin_amdgcn_sched_barrier(0);
+        uint16_t ph[4], pl[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sp_split(sv[nb][r], ph[r], pl[r]);
+        const uint2v pbh = uint2v{(uint32_t)ph[0] | ((uint32_t)ph[1] << 16), (uint32_t)ph[2] | ((uint32_t)ph[3] << 16)};
+        const uint2v pbl = uint2v{(uint32_t)pl[0] | ((uint32_t)pl[1] << 16), (uint32_t)pl[2] | ((uint32_t)pl[3] << 16)};
+#pragma unroll
+        for (int d = 0; d < DB; ++d) {
+          ot[d] = mfma_16x16x16<bf16>(__builtin_bit_cast(short4v, vtl[d]), __builtin_bit_cast(short4v, pbh), ot[d]);
+          ot[d] = mfma_16x16x16<bf16>(__builtin_bit_cast(short4v, vth[d]), __builtin_bit_cast(short4v, pbl), ot[d]);
+          ot[d] = mfma_16x16x16<bf16>(__builtin_bit_cast(short4v, vth[d]), __builtin_bit_cast(short4v, pbh), ot[d]);
+        }
+      }
+    }
+    __syncthreads();  // K / V tiles free for the next iteration
+  }
+  l_run += __shfl_xor(l_run, 16, 64);
+  l_run += __shfl_xor(l_run, 32, 64);
+  if (q_ok) {
+    const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+    float* Obf = reinterpret_cast<float*>(a.O) + (int64_t)b * a.o_bs + (int64_t)h * a.o_hs + (int64_t)iq * a.o_rs;
+#pragma unroll
+    for (int d = 0; d < DB; ++d) {
+      const float4v v = ot[d] * inv;
+      const int c = d * 16 + 4 * g;
+      if (a.o_split)
+        st4<sp16>(reinterpret_cast<sp16*>(a.O) + (int64_t)b * a.o_bs + (int64_t)iq * a.o_rs, (int)(h * a.o_hs) + c, v[0], v[1], v[2], v[3]);
+      else
+        *reinterpret_cast<float4v*>(Obf + c) = v;
+    }
+  }
+}
+template <int HD, int NWV, int BKV>
+__global__ __launch_bounds__(NWV * 64) void attn_sp_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  attn_sp_body<HD, NWV, BKV>(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, smem);
+}
+template <int HD, int NWV, int BKV>
+static void attn_sp_launch_cfg(const AttnArgs& a, hipStream_t s) {
+  constexpr int BQ = 16 * NWV, HDK = (HD + 31) / 32 * 32, LDK = HDK + 8, LDV = ((HD * 2 + 255) / 256 * 256 + 32) / 2;
+  size_t lds = 2 * 2 * (size_t)(BKV * LDK + BKV * LDV);
+  if (a.rel_h || a.rel_p) lds += sizeof(float) * BQ * (a.kh + a.kw);
+  if (lds > 160 * 1024) throw std::runtime_error("split-pair attention: LDS budget exceeded");
+  auto kern = &attn_sp_kernel<HD, NWV, BKV>;
+  static KernelAttrOnce once;
+  ensure_dyn_lds(once, reinterpret_cast<const void*>(kern), 160 * 1024);
+  static const std::string tag = "attn_sp16_hd" + std::to_string(HD) + "_w" + std::to_string(NWV);
+  const double flops = 4.0 * a.B * a.H * (double)a.Sq * a.Sk * HD * (a.causal ? 0.5 : 1.0);
+  const double bytes = (double)a.B * a.H * HD * 4.0 * (2.0 * a.Sq + 2.0 * a.Sk);
+  ProfScope prof(tag.c_str(), flops, bytes, s);
+  hipLaunchKernelGGL(kern, dim3(cdiv(a.Sq, BQ), a.H, a.B), dim3(NWV * 64), lds, s, a);
+}
+// whether launch_attention<float> takes the split-pair kernel for this call (AttnArgs::sp16 set by the caller)
+static bool attn_sp_takes(const AttnArgs& a) {
+  static const bool off = getenv("ANYREF_NO_SP16_ATTN") != nullptr;  // lab knob: the f32-MFMA kernel instead
+  if (off || !a.sp16 || (a.hd != 64 && a.hd != 80 && a.hd != 128)) return false;
+  if (a.rel_tab_h || (a.o_f32 && a.o_split)) return false;
+  if ((a.rel_h || a.rel_p) && (a.kw > 64 || a.kh * a.kw > 4096)) return false;  // (the multiply-shift j / kw)
+  if (a.o_rs % 4 || a.o_hs % 4 || a.o_bs % 4 || ((uintptr_t)a.O & 15)) return false;
+  return true;
+}
+template <int HD>
+static void attn_sp_launch(const AttnArgs& a, hipStream_t s) {
+  if (a.Sq >= 1024 && !a.causal) attn_sp_launch_cfg<HD, 8, 64>(a, s);                       // SAM global attention
+  else if (HD == 80 && a.Sq > 192 && a.Sq <= 224 && !a.causal) attn_sp_launch_cfg<HD, 7, 80>(a, s);  // 14 x 14 windows: 2 x 112 queries
+  else attn_sp_launch_cfg<HD, 4, 64>(a, s);
+}
+
 template <typename T, int HD, int NWV = 4, int BKV_ = 0, int NRES = 0>
 __global__ __launch_bounds__(NWV * 64) void attn_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1100,6 +1402,14 @@ void launch_attention(const AttnArgs& a, hipStream_t s) {
   if (a.q_rs % VEC || a.k_rs % VEC || a.v_rs % VEC || a.q_hs % VEC || a.k_hs % VEC || a.v_hs % VEC ||
       a.q_bs % VEC || a.k_bs % VEC || a.v_bs % VEC)
     throw std::runtime_error("attention: strides must be multiples of 16 bytes");
+  if constexpr (std::is_same<T, float>::value) {
+    if (attn_sp_takes(a)) {
+      if (a.hd == 64) attn_sp_launch<64>(a, s);
+      else if (a.hd == 80) attn_sp_launch<80>(a, s);
+      else attn_sp_launch<128>(a, s);
+      return;
+    }
+  }
   switch (a.hd) {
     case 16: attn_launch<T, 16>(a, s); break;
     case 32: attn_launch<T, 32>(a, s); break;

@@ -260,6 +260,9 @@ struct AttnArgs {
   // 1 (T = float only): O is a split-pair matrix (common.h sp16: the A operand of the GEMM that follows in
   // ANYREF_MODE_PARITY16); o_bs / o_rs are whole matrix rows (multiples of 64 elements), o_hs % 4 == 0
   int o_split = 0;
+  // 1 (T = float only, head dim 64 / 80 / 128): the f32 operands are multiplied as bf16 PAIRS on the 16-bit MFMA (three
+  // passes per product, attention.hip attn_sp_body) instead of the f32 MFMA -- same f32-level result at 3/16 of the MFMA time
+  int sp16 = 0;
   int max_wg = 0;  // > 0: at most this many workgroups (bf16, head dim 80, the SAM forms); each walks several blocks
   // set by the launcher: keys split over kv_splits workgroups per query block, partials merged afterwards
   int kv_splits = 1;

@@ -1191,7 +1191,7 @@ void Model<T, TS>::clip_tower(hipStream_t s, const float* images, int B) {
     a.o_bs = (int64_t)S * Dc; a.o_rs = Dc; a.o_hs = hd;
     a.B = B; a.H = c.clip_heads; a.Sq = S; a.Sk = S; a.hd = hd;
     a.scale = 1.f / sqrtf((float)hd);
-    a.o_split = SPT;
+    a.o_split = SPT; a.sp16 = SPT;
     launch_attention<Q>(a, s);
     // the two LayerNorms of a block ride on the split-K reductions of the GEMMs in front of them (perf mode)
     if (!gemm(s, c_att_, Dc, L.out, c_x_, Dc, R, ACT_NONE, true, c_x_, Dc, nullptr, &L.ln2, c_h_, false, c.clip_eps))
@@ -1246,7 +1246,7 @@ void Model<T, TS>::audio_encode(hipStream_t s, const float* mel, int n, float* e
     a.o_bs = (int64_t)RS * D; a.o_rs = D; a.o_hs = hd;
     a.B = n; a.H = nh; a.Sq = St; a.Sk = St + 1; a.hd = hd;
     a.scale = 1.f / sqrtf((float)hd);
-    a.o_split = SPT;
+    a.o_split = SPT; a.sp16 = SPT;
     launch_attention<Q>(a, s);
     gemm(s, a_att_, D, Bk.out, a_x_, D, R, ACT_NONE, true, a_x_, D);
     norm(s, a_x_, D, Bk.ln2, a_h_, D, R, D, 1e-6f, false);
@@ -1306,7 +1306,7 @@ void Model<T, TS>::llm_prefill(hipStream_t s, int B, int Sp, const int* lens_dev
     a.B = B; a.H = nh; a.Sq = Sp; a.Sk = Sp; a.hd = hd;
     a.scale = 1.f / sqrtf((float)hd);
     a.causal = 1; a.kv_len = lens_dev; a.q_len = lens_dev;
-    a.o_split = SPT;
+    a.o_split = SPT; a.sp16 = SPT;
     launch_attention<Q>(a, s);
     if (!gemm(s, l_att_, H, L.o, l_x_, H, R, ACT_NONE, true, l_x_, H, nullptr, &L.post_norm, l_h_))
       norm(s, l_x_, H, L.post_norm, l_h_, H, R, H, c.llm_rms_eps, false, true);
@@ -1449,7 +1449,7 @@ void Model<T, TS>::sam_encoder(hipStream_t s, const float* images, int B, float*
     a.q_rs = a.k_rs = a.v_rs = 3 * D; a.o_rs = D;
     a.H = nh; a.hd = hd; a.scale = 1.f / sqrtf((float)hd);
     a.Q = s_qkv_; a.K = s_qkv_ + D; a.V = s_qkv_ + 2 * D; a.O = s_att_;
-    a.o_split = SPS;
+    a.o_split = SPS; a.sp16 = SPS;
     // decomposed rel-pos bias: P = q . [rel_pos_h | rel_pos_w]^T for every head in ONE batched MFMA GEMM
     // (batch = heads, A = the q columns of the fused qkv buffer); the attention kernel applies the shift.
     auto rel_gemm = [&](int rows) {

@@ -117,7 +117,7 @@ int anyref_op_attention(int t, void* stream, const void* q, const void* k, const
     if (t == 3) {  // f32 operands, pair-typed output rows [B*Sq, H*hd] (H*hd % 64 == 0); o gets hi + lo
       if ((H * hd) % 64) throw std::runtime_error("op_attention t=3: H * hd % 64 != 0");
       TmpBuf Os((size_t)B * Sq * H * hd * 4);
-      a.O = Os.p; a.o_split = 1;
+      a.O = Os.p; a.o_split = 1; a.sp16 = 1;
       launch_attention<float>(a, (hipStream_t)stream);
       launch_unsplit(Os.p, H * hd, reinterpret_cast<float*>(o), H * hd, B * Sq, H * hd, (hipStream_t)stream);
     } else
@@ -162,6 +162,13 @@ int anyref_op_attention_relp(int t, void* stream, const void* q, const void* k, 
     a.q_rs = a.k_rs = a.v_rs = a.o_rs = H * hd; a.q_hs = a.k_hs = a.v_hs = a.o_hs = hd;
     a.B = B; a.H = H; a.Sq = S; a.Sk = S; a.hd = hd; a.scale = scale;
     a.rel_p = rel_p; a.rel_ld = rel_ld; a.rel_hs = (int64_t)B * S * rel_ld; a.kh = kh; a.kw = kw;
+    if (t == 3) {  // split-pair attention: f32 operands, pair-typed output rows; o gets hi + lo
+      if ((H * hd) % 64) throw std::runtime_error("op_attention_relp t=3: H * hd % 64 != 0");
+      TmpBuf Os((size_t)B * S * H * hd * 4);
+      a.O = Os.p; a.o_split = 1; a.sp16 = 1;
+      launch_attention<float>(a, (hipStream_t)stream);
+      launch_unsplit(Os.p, H * hd, reinterpret_cast<float*>(o), H * hd, B * S, H * hd, (hipStream_t)stream);
+    } else
     if (t == 0) launch_attention<float>(a, (hipStream_t)stream);
     else if (t == 2) launch_attention<f16>(a, (hipStream_t)stream);
     else launch_attention<bf16>(a, (hipStream_t)stream);

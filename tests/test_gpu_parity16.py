@@ -168,6 +168,47 @@ def test_split_pair_attention_output(lib, B, H, Sq, Sk, hd, causal):
     close(o, ref, 2e-5, "attention")
 
 
+@pytest.mark.parametrize("B,H,size", [(1, 4, 64), (2, 4, 32), (3, 4, 14)])
+def test_split_pair_attention_with_rel_pos_bias(lib, B, H, size):
+    """SAM attention as parity16 runs it (image_encoder.py:231-260, 354-392): f32 q / k / v multiplied as bf16 pairs (three
+    16-bit MFMA passes per product), the decomposed rel-pos bias from the P buffer of the f32 rel-pos GEMM; size 64 = the
+    global layers (key tile = one bias row), 14 = the windows (196 tokens, two query blocks), 32 = the general path."""
+    from test_gpu_ops import ref_attention
+    hd = 80
+    g = torch.Generator().manual_seed(B * 11 + H + size)
+    S = size * size
+    q, k, v = (torch.randn(B, S, H, hd, generator=g) for _ in range(3))
+    th, tw = torch.randn(2 * size - 1, hd, generator=g) * 0.3, torch.randn(2 * size - 1, hd, generator=g) * 0.3
+    idx = torch.arange(size)[:, None] - torch.arange(size)[None, :] + size - 1
+    rq = q.double().permute(0, 2, 1, 3).reshape(B, H, size, size, hd)
+    rel_h = torch.einsum("bnhwc,hkc->bnhwk", rq, th.double()[idx]).reshape(B, H, S, size)
+    rel_w = torch.einsum("bnhwc,wkc->bnhwk", rq, tw.double()[idx]).reshape(B, H, S, size)
+    scale = hd ** -0.5
+    ref = ref_attention(q.double(), k.double(), v.double(), scale, False, None, rel_h, rel_w, size)
+    npad = 2 * size
+    p = torch.zeros(H, B * S, 2 * npad, dtype=torch.float64)
+    qh = q.double().permute(2, 0, 1, 3).reshape(H, B * S, hd)
+    p[:, :, : 2 * size - 1] = qh @ th.double().t()
+    p[:, :, npad: npad + 2 * size - 1] = qh @ tw.double().t()
+    o = torch.empty(B, S, H, hd, device="cuda")
+    check(lib, lib.anyref_op_attention_relp(SP, None, P(q.cuda()), P(k.cuda()), P(v.cuda()), P(o), B, H, S, hd, scale,
+                                            P(p.float().cuda().contiguous()), 2 * npad, size, size))
+    close(o, ref, 2e-5, f"rel-pos attention size {size}")
+
+
+def test_split_pair_attention_ragged_kv_len(lib):
+    from test_gpu_ops import ref_attention
+    B, H, Sq, Sk, hd = 3, 4, 100, 300, 128
+    g = torch.Generator().manual_seed(77)
+    q, k, v = (torch.randn(B, s, H, hd, generator=g) for s in (Sq, Sk, Sk))
+    kv_len = torch.tensor([300, 131, 64], dtype=torch.int32)
+    ref = ref_attention(q.double(), k.double(), v.double(), hd ** -0.5, False, kv_len, None, None, 0)
+    o = torch.empty(B, Sq, H, hd, device="cuda")
+    check(lib, lib.anyref_op_attention(SP, None, P(q.cuda()), P(k.cuda()), P(v.cuda()), P(o), B, H, Sq, Sk, hd, hd ** -0.5, 0,
+                                       P(kv_len.cuda()), None, None, 0, 0))
+    close(o, ref, 2e-5, "ragged kv_len")
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # end to end
 # ---------------------------------------------------------------------------------------------------------------------
