@@ -1152,9 +1152,19 @@ static bool attn_sp_takes(const AttnArgs& a) {
 }
 template <int HD>
 static void attn_sp_launch(const AttnArgs& a, hipStream_t s) {
-  if (a.Sq >= 1024 && !a.causal) attn_sp_launch_cfg<HD, 8, 64>(a, s);                       // SAM global attention
-  else if (HD == 80 && a.Sq > 192 && a.Sq <= 224 && !a.causal) attn_sp_launch_cfg<HD, 7, 80>(a, s);  // 14 x 14 windows: 2 x 112 queries
-  else attn_sp_launch_cfg<HD, 4, 64>(a, s);
+  if (a.Sq >= 1024 && !a.causal) {  // SAM global attention
+    attn_sp_launch_cfg<HD, 8, 64>(a, s);
+    return;
+  }
+  if constexpr (HD == 80) {
+    // 14 x 14 windows (196 tokens): 2 x 112 queries, 3 key tiles of 80 (one 13-wave block per window-head would stage K / V
+    // once, but 13 waves leave 128 VGPRs each: 132 - 204 bytes of scratch in every tile size tried)
+    if (a.Sq > 192 && a.Sq <= 224 && !a.causal) {
+      attn_sp_launch_cfg<HD, 7, 80>(a, s);
+      return;
+    }
+  }
+  attn_sp_launch_cfg<HD, 4, 64>(a, s);
 }
 
 template <typename T, int HD, int NWV = 4, int BKV_ = 0, int NRES = 0>

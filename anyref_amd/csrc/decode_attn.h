@@ -53,7 +53,9 @@ __device__ __forceinline__ void decode_attn_body(const float* __restrict__ qkv, 
                                                  T* __restrict__ vc, int maxS, int H, float scale,
                                                  float* __restrict__ out, T* __restrict__ q_keep, int h, int b,
                                                  float* sm) {
-  constexpr int NT = 512, UN = 4;
+  // sweeps per batch: f32 rows are twice the bytes and LPK = 32 lanes share a key, so a batch of 4 sweeps is 64 keys
+  // (bf16: 128): 6 sweeps take a ~330-key context in four batches (round trips) instead of six (8 sweeps spill)
+  constexpr int NT = 512, UN = sizeof(T) == 2 ? 4 : 6;
   constexpr int VEC = Vec16<T>::N, LPK = HD / VEC, KPI = NT / LPK, HALF = HD / 2;
   static_assert(LPK <= 64 && (LPK & (LPK - 1)) == 0, "lanes per key must be a power of two within a wave");
   float* q_s = sm;                 // [HD] rotated, T-rounded, pre-scaled query

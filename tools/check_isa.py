@@ -26,13 +26,13 @@ def asm_of(src, strict):
 def main():
     bad = 0
     allowed_scratch = ()
-    for src in ("gemm.hip", "gemm_f16.hip", "gemv.hip", "attention.hip", "ops.hip"):
-        s = asm_of(src, strict=src in ("gemm.hip", "gemm_f16.hip", "gemv.hip"))
+    for src in ("gemm.hip", "gemm_f16.hip", "gemm_sp16.hip", "gemv.hip", "attention.hip", "ops.hip"):
+        s = asm_of(src, strict=src in ("gemm.hip", "gemm_f16.hip", "gemm_sp16.hip", "gemv.hip"))
         for name, seg in re.findall(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)", s):
             if int(seg) > 0 and not any(a in name for a in allowed_scratch):
                 print(f"FAIL {src}: {name} uses {seg} bytes of scratch")
                 bad += 1
-        if src in ("gemm.hip", "gemm_f16.hip"):
+        if src in ("gemm.hip", "gemm_f16.hip", "gemm_sp16.hip"):
             for m in re.finditer(r"^(_ZN6anyref16gemm_glds_kernel\S*):\n(.*?)\.Lfunc_end", s, re.S | re.M):
                 lines = m.group(2).split("\n")
                 n = sum(1 for k, l in enumerate(lines)
