@@ -979,7 +979,9 @@ void launch_gemm(const GemmArgs& a_in, hipStream_t s) {
     if (a.swiglu_pairs) a.vec_ok = (a.N % 4 == 0 && a.ldc % 2 == 0 && !((uintptr_t)a.C & 3) && (!a.col_scale || !((uintptr_t)a.col_scale & 15))) ? 1 : 0;
   }
   const double flops = 2.0 * a.M * a.N * (double)a.K * a.batch;
-  const double bytes = ((double)a.M * a.K + (double)a.N * a.K) * sizeof(T) * a.batch +
+  // algorithmic bytes: A (pairs: 4 bytes per element), W as stored (fp8: 1 byte, pairs mode: bf16), C
+  const double wbytes = a.w_fp8 ? 1.0 : (SP ? 2.0 : (double)sizeof(T));
+  const double bytes = ((double)a.M * a.K * sizeof(T) + (double)a.N * a.K * wbytes) * a.batch +
                        (double)a.M * a.N * (a.c_f32 ? 4 : sizeof(T)) * a.batch;
   if (a.w_fp8 && (sizeof(T) != 2 || a.K % 64 || knobs().no_glds || knobs().tile >= 0))
     throw std::runtime_error("gemm: an fp8 weight operand needs the bf16 LDS-DMA kernel (K % 64 == 0)");
@@ -1000,8 +1002,8 @@ void launch_gemm(const GemmArgs& a_in, hipStream_t s) {
             const int tiles_m8 = cdiv(a.M, BM), nwg8 = tiles_m8 * cdiv(a.N, BN);
             int gm8 = (int)lround(sqrt((double)(nwg8 > 8 ? nwg8 / 8 : 1)));
             a.group_m = gm8 < 1 ? 1 : (gm8 > tiles_m8 ? tiles_m8 : gm8);
-            char tag8[48];
-            snprintf(tag8, sizeof(tag8), "%s_fp8w", tag);
+            char tag8[56];
+            snprintf(tag8, sizeof(tag8), "%s_fp8w%s", tag, a.M <= 16 ? "_dec" : "");  // _dec: decode rows (weight streaming)
             ProfScope prof(tag8, flops, bytes, s);
             hipLaunchKernelGGL(kern8, dim3(nwg8, 1, a.batch), dim3(WM * WN * 64), NS * ((size_t)BM * 128 + (size_t)BN * 64),
                                s, a);
@@ -1017,9 +1019,12 @@ void launch_gemm(const GemmArgs& a_in, hipStream_t s) {
           gm = gm < 1 ? 1 : (gm > tiles_m ? tiles_m : gm);
           a.group_m = knobs().gm >= 0 ? knobs().gm : gm;
         }
-        char tagt[48];
-        snprintf(tagt, sizeof(tagt), SP ? "gemm_sp16_%s" : "gemm_f16_%s", tag + 10);  // gemm_bf16_... -> gemm_f16_... / gemm_sp16_...
-        ProfScope prof(is_half16<T>::value || SP ? tagt : tag, flops, bytes, s);
+        // gemm_bf16_... -> gemm_f16_... / gemm_sp16_...; "_dec": at most 16 rows (the MFMA decode path: HBM-bound weight streaming,
+        // booked apart from the MFMA-bound prefill launches of the same tile)
+        char tagt[56];
+        snprintf(tagt, sizeof(tagt), "%s%s%s", SP ? "gemm_sp16_" : is_half16<T>::value ? "gemm_f16_" : "gemm_bf16_", tag + 10,
+                 a.M <= 16 ? "_dec" : "");
+        ProfScope prof(tagt, flops, bytes, s);
         dim3 grid(cdiv(a.N, BN) * cdiv(a.M, BM), 1, a.batch);
         if constexpr (BM <= 256 && BM >= 128) {  // the SAM encoder's tiles
           // (tiles small enough for two workgroups per CU -- 128 x 128 on two stages: 64 KB -- take twice the cap: the
