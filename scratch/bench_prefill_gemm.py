@@ -13,9 +13,11 @@ for M, N, K in [(320, 22016, 4096), (320, 12288, 4096), (320, 4096, 4096), (320,
     def run(i): return lib.anyref_op_gemm(1, None, P(A), P(Ws[i % nb]), None, P(Cc), None, None, M, N, K, 0, 0)
     for i in range(nb): assert run(i) == 0
     torch.cuda.synchronize()
+    ref = A.float() @ Ws[(nb - 1) % nb][:, :K].float().t()
+    err = (Cc.float() - ref).abs().max().item() / ref.abs().max().item()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for i in range(40): run(i)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 40
-    print(f"pad {pad:4d} {M:5d} {N:6d} {K:6d} {ms*1e3:8.1f} us  {2*M*N*K/ms/1e9:7.1f} TF", flush=True)
+    print(f"pad {pad:4d} {M:5d} {N:6d} {K:6d} {ms*1e3:8.1f} us  {2*M*N*K/ms/1e9:7.1f} TF  rel err {err:.1e}", flush=True)

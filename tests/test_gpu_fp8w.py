@@ -43,7 +43,11 @@ def test_quantiser_bit_exact(N, K):
 
 
 @pytest.mark.parametrize("B,N,K,dual,norm", [(1, 512, 256, False, True), (2, 96, 688, False, False),
-                                              (1, 688, 256, True, True), (4, 40, 4096, False, True)])
+                                              (1, 688, 256, True, True), (4, 40, 4096, False, True),
+                                              # 5 .. 8 rows: the matrix-core GEMV (gemv_mfma_kernel, fp8 weights widened per
+                                              # fragment); K = 13824: down_proj at 13B, taken as K chunks (x stage of 8 rows)
+                                              (8, 1000, 5120, False, True), (8, 688, 5120, True, True), (5, 100, 256, False, False),
+                                              (8, 5120, 13824, False, False), (6, 130, 11008, False, False)])
 def test_gemv_fp8_vs_torch(B, N, K, dual, norm):
     lib = _lib.load()
     g = torch.Generator().manual_seed(B * N + K)
