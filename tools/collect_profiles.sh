@@ -23,6 +23,17 @@ rocprofv3 --kernel-trace --output-format csv -d $W/kt0 -o kt0 -- python3 tools/p
 python3 tools/trace_summary.py $W/kt0 5 45 > "$OUT/kernels_by_grid_overlap_off.txt" || exit 8
 rocprofv3 --kernel-trace --output-format csv -d $W/kt1 -o kt1 -- python3 tools/prof_c2.py --iters 3 --overlap > /dev/null 2>&1 || exit 9
 python3 tools/trace_summary.py $W/kt1 5 --overlap gemv_kernel > "$OUT/overlap_under_rocprof.txt" || exit 10
+# the tolerance-meeting mode (parity16), overlap off: per-kernel durations of one C2 generate
+rocprofv3 --kernel-trace --stats --output-format csv -d $W/p16 -o p16 -- python3 tools/prof_mode.py parity16 --iters 3 > $W/p16.log 2>&1 || exit 11
+cp $W/p16/p16_kernel_stats.csv "$OUT/parity16_kernel_stats.csv" 2>/dev/null || cp $(ls $W/p16/*kernel_stats.csv $W/p16/*/*kernel_stats.csv 2>/dev/null | head -1) "$OUT/parity16_kernel_stats.csv"
+# SQ counters per kernel on the final build (8 SQ slots per pass; program directly after `--`): where the wave cycles go, MFMA-busy
+# cycles, LDS bank conflicts / LDS issue stalls -- overlap off, perf mode
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY --output-format csv -d $W/sq1 -- python3 tools/prof_c2.py --iters 1 > $W/sq1.log 2>&1 || exit 12
+python3 tools/pmc_sq_summary.py $W/sq1 40 > "$OUT/pmc_sq_per_kernel.txt" || exit 13
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_MFMA SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $W/sq2 -- python3 tools/prof_c2.py --iters 1 > $W/sq2.log 2>&1 \
+  && python3 tools/pmc_sq_summary.py $W/sq2 40 > "$OUT/pmc_sq_mfma_ops_per_kernel.txt"
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY --output-format csv -d $W/sq3 -- python3 tools/prof_mode.py parity16 --iters 1 > $W/sq3.log 2>&1 \
+  && python3 tools/pmc_sq_summary.py $W/sq3 30 > "$OUT/pmc_sq_per_kernel_parity16.txt"
 python3 - "$W" "$OUT" <<'PY'
 import collections, csv, glob, sys
 w, out = sys.argv[1], sys.argv[2]

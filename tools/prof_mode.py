@@ -1,5 +1,5 @@
 """One C2 generate per iteration in a given arithmetic mode, overlap off (clean per-kernel durations under rocprofv3).
-python scratch/prof_mode.py MODE [--iters N] [--fan-in]"""
+python tools/prof_mode.py MODE [--iters N] [--fan-in]"""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from anyref_amd.config import config_7b
