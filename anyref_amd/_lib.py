@@ -78,6 +78,7 @@ SYMBOLS = {
                                 C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "anyref_stamps_enable": (_I, [_P, _I]),
     "anyref_stamps_collect": (_I, [_P, C.POINTER(_L)]),
+    "anyref_stamps_dropped": (_I, [_P, C.POINTER(_L)]),
     "anyref_stamps_read": (_I, [_P, _L, C.c_char_p, _I, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                C.POINTER(C.c_double), C.POINTER(_I)]),
     "anyref_stamps_spread": (_I, [_P, _L, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),

@@ -173,6 +173,12 @@ int anyref_profile_read(anyref_handle* h, int idx, char* name, int cap, double* 
 
 int anyref_stamps_enable(anyref_handle* h, int on) { GUARD(h, h->m->stamp.enable(on != 0)); }
 
+int anyref_stamps_dropped(anyref_handle* h, int64_t* count) {
+  GUARD(h, {
+    if (!count) throw std::runtime_error("null argument");
+    *count = h->m->stamp.dropped();
+  });
+}
 int anyref_stamps_collect(anyref_handle* h, int64_t* count) {
   GUARD(h, {
     h->stamp_rows = h->m->stamp.collect();

@@ -85,8 +85,14 @@ class Stamper {
   StampArgs slot(const char* tag, double bytes, int grid);
   void graph_begin(int key);          // the launches up to graph_end() are being captured under `key`
   void graph_end(hipStream_t cap);    // appends the epoch bump to the captured stream
+  void graph_abort();                 // the capture under way failed: forget its launches, back to eager bookkeeping
+  // launches that could not be stamped (record full) + graph replays past the epoch capacity since enable / the last collect
+  int64_t dropped() const { return dropped_; }
   bool graph_known(int key) const { return graphs_.count(key) != 0; }
-  void graph_replayed(int key) { epoch_keys_.push_back(key); }
+  void graph_replayed(int key) {
+    if ((int)epoch_keys_.size() < max_epoch_) epoch_keys_.push_back(key);
+    else ++dropped_;  // (the device side stops recording at max_epoch too)
+  }
   std::vector<StampRow> collect();    // after the device has been synchronised; also resets the counters
  private:
   struct Rec { std::string tag; double bytes; int grid; size_t off; };
@@ -96,6 +102,7 @@ class Stamper {
   int max_epoch_ = 0;
   int capturing_ = -1;
   size_t cap_used_ = 0;
+  int64_t dropped_ = 0;
   std::vector<Rec> eager_;
   std::map<int, std::vector<Rec>> graphs_;
   std::vector<int> epoch_keys_;

@@ -464,6 +464,20 @@ class Model : public ModelBase {
     HIP_TRY(hipEventRecord(stage_ev_[r], s));
     stage_busy_[r] = true;
   }
+  // stage_begin ... copies ... stage_end, with the event recorded on EVERY exit: a throw between the first queued copy and
+  // stage_end must not leave the region marked free while a copy still reads it
+  struct StageScope {
+    Model* m;
+    int r;
+    hipStream_t s;
+    StageScope(Model* m_, int r_, hipStream_t s_) : m(m_), r(r_), s(s_) { m->stage_begin(r); }
+    ~StageScope() {
+      try {
+        m->stage_end(r, s);
+      } catch (...) {
+      }
+    }
+  };
 
   // ---- ImageBind audio trunk (f-4; present iff cfg.aud_blocks > 0) ----
   struct AudBlock {
@@ -1149,6 +1163,7 @@ void Model<T, TS>::decode_step_graph(hipStream_t s, int B, bool keep_q, bool cor
       llm_decode_step(cap_stream_, B, keep_q);
       if (stamped) stamp.graph_end(cap_stream_);
     } catch (...) {
+      if (stamped) stamp.graph_abort();  // or every later eager GEMV would be booked as a slot of this dead graph
       hipStreamEndCapture(cap_stream_, &g);
       if (g) hipGraphDestroy(g);
       throw;
@@ -1439,6 +1454,7 @@ void Model<T, TS>::sam_encoder(hipStream_t s, const float* images, int B, float*
     a.C = s_x_; a.ldc = D; a.M = NT; a.N = D; a.K = sam_patch_.k; a.c_f32 = 1;
     a.resid = sam_pos_; a.ldr = D;  // + absolute position embedding, shared by every image
     a.batch = B; a.sA = (int64_t)NT * sam_patch_.k; a.sC = (int64_t)NT * D; a.sR = 0;
+    a.max_wg = cap_wg_;  // (honoured at batch 1, where the CU share is in use)
     launch_gemm<TS>(a, s);
   }
   for (int bi = blk0; bi < blk1; ++bi) {
@@ -1457,6 +1473,7 @@ void Model<T, TS>::sam_encoder(hipStream_t s, const float* images, int B, float*
       r.A = s_qkv_; r.lda = 3 * D; r.sA = hd; r.W = L.rel.w; r.ldw = L.rel.k; r.sW = 0;
       r.C = s_relh_; r.ldc = L.rel.n; r.sC = (int64_t)rows * L.rel.n; r.M = rows; r.N = L.rel.n; r.K = L.rel.k;
       r.c_f32 = 1; r.batch = nh;
+      // (exempt from the side-stream CU share: a batched launch has no capped form; ~1024 short workgroups, 4 launches per image)
       launch_gemm<QS>(r, s);
       a.rel_p = s_relh_; a.rel_ld = L.rel.n; a.rel_hs = (int64_t)rows * L.rel.n;
     };
@@ -1677,7 +1694,8 @@ int Model<T, TS>::splice_inputs(hipStream_t s, const int64_t* input_ids, const i
                       H, slen_dev_, s);
   if (n_extra > 0) {
     if (n_extra > (int)cfg.max_batch * std::max(cfg.max_seg, 64)) throw std::runtime_error("too many extra slots");
-    stage_begin(ST_EXTRA);
+    {
+    StageScope stage_scope(this, ST_EXTRA, s);
     int *eb = stage_extra_, *ep = stage_extra_ + n_extra;  // pinned: the copies below need no host wait
     for (int i = 0; i < n_extra; ++i) {
       const int b = extra_slots[2 * i], p = extra_slots[2 * i + 1];
@@ -1687,7 +1705,7 @@ int Model<T, TS>::splice_inputs(hipStream_t s, const int64_t* input_ids, const i
     }
     HIP_TRY(hipMemcpyAsync(idx_a_, eb, n_extra * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(idx_b_, ep, n_extra * 4, hipMemcpyHostToDevice, s));
-    stage_end(ST_EXTRA, s);
+    }
     launch_scatter_rows(extra_embeds, idx_a_, idx_b_, n_extra, l_x_, Sp, H, s);
   }
   return Sp;
@@ -1797,18 +1815,18 @@ void Model<T, TS>::run_tail(hipStream_t s, const float* sam_images, int B, const
   if (off > out_masks_cap) throw std::runtime_error("out_masks capacity too small");
   if (done > nseg) throw std::runtime_error("internal: more early [SEG] masks than [SEG] tokens");
   if (nseg == done) return;
-  stage_begin(ST_SEG);
-  for (int i = 0; i < nseg; ++i) {
-    stage_seg_[i] = seg_b[i];
-    stage_seg_[nseg + i] = seg_pos[i];
+  {
+    StageScope stage_scope(this, ST_SEG, s);
+    for (int i = 0; i < nseg; ++i) {
+      stage_seg_[i] = seg_b[i];
+      stage_seg_[nseg + i] = seg_pos[i];
+    }
+    HIP_TRY(hipMemcpyAsync(idx_a_, stage_seg_, nseg * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(idx_b_, stage_seg_ + nseg, nseg * 4, hipMemcpyHostToDevice, s));
   }
-  HIP_TRY(hipMemcpyAsync(idx_a_, stage_seg_, nseg * 4, hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemcpyAsync(idx_b_, stage_seg_ + nseg, nseg * 4, hipMemcpyHostToDevice, s));
-  stage_end(ST_SEG, s);
   launch_gather_rows(hidden_all_, S, H, idx_a_, idx_b_, nseg, seg_h_, s);
   if (c.rephrase_weight > 0.f) {
-    stage_begin(ST_KL);
-    bool kl_used = false;
+    StageScope stage_scope(this, ST_KL, s);  // (the event is recorded at the end of this block whether or not a copy was queued)
     // anyref.py:735-755,767-769: the first [SEG] of image i gets + w * sum_j attn_j * hidden_j
     const int nh = c.llm_heads, hd = H / nh;
     Q* kc = kcache_ + cache_layer_stride_ * (c.llm_layers - 1);
@@ -1825,14 +1843,12 @@ void Model<T, TS>::run_tail(hipStream_t s, const float* sam_images, int B, const
       } else {
         stage_kl_[b] = e0 + 1;
         HIP_TRY(hipMemcpyAsync(kvlen_dev_ + b, stage_kl_ + b, 4, hipMemcpyHostToDevice, s));
-        kl_used = true;
         launch_attn_row_mean<Q>(q_last_ + ((size_t)b * S + e0) * H, 0, hd, kc + (size_t)b * S * H, 0, H, hd,
                                 kvlen_dev_ + b, 1, nh, hd, 1.f / sqrtf((float)hd), attn_row_ + (size_t)b * S, S, s);
       }
       launch_rephrase(hidden_all_ + (size_t)b * S * H, H, attn_row_ + (size_t)b * S, s0, e0, c.rephrase_weight,
                       seg_h_ + (size_t)i * H, s);
     }
-    if (kl_used) stage_end(ST_KL, s);
   }
   gemmf(s, seg_h_, H, fc1_, seg_t_, H, nseg, ACT_RELU);
   gemmf(s, seg_t_, H, fc2_, pred_emb_, c.out_dim, nseg, ACT_NONE);
@@ -1881,7 +1897,10 @@ void Model<T, TS>::generate(hipStream_t s, const float* clip_images, const float
   // than the loop can hide at a reduced share: queued whole, uncapped, after prefill.
   const int nblk = (int)sam_blocks_.size();
   static const bool any_b = getenv("ANYREF_SIDE_ANYB") != nullptr;  // lab: the CU share for batches > 1 too
-  const bool fed = (B == 1 || any_b) && side_wgs_ > 0 && overlap_ && sizeof(T) == 2;
+  // (the split-pair mode too: its GEMMs have the capped forms; its attention launches stay uncapped.  Same share / step
+  //  count as perf, alternated on one box: 57.1 - 57.3 ms uncapped-after-prefill -> 52.7 - 53.3 ms fed; 160 / 192 / 96 workgroups
+  //  or 9 steps: 53.2 - 55.8)
+  const bool fed = (B == 1 || any_b) && side_wgs_ > 0 && overlap_ && IS16;
   const int per_step = std::max(1, (nblk + side_steps_ - 1) / std::max(1, side_steps_));
   if (fed) {
     fork_sam(s, sam_images, B, true);
@@ -1904,7 +1923,8 @@ void Model<T, TS>::generate(hipStream_t s, const float* clip_images, const float
   }
   // first token: logits of the last prompt row of every sequence
   {
-    stage_begin(ST_FIRST);
+    {
+    StageScope stage_scope(this, ST_FIRST, s);
     int *bb = stage_first_, *pp = stage_first_ + B, *sl = stage_first_ + 2 * B;
     for (int b = 0; b < B; ++b) {
       bb[b] = b;
@@ -1914,7 +1934,7 @@ void Model<T, TS>::generate(hipStream_t s, const float* clip_images, const float
     HIP_TRY(hipMemcpyAsync(idx_a_, bb, B * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(idx_b_, pp, B * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(pos_dev_, sl, B * 4, hipMemcpyHostToDevice, s));
-    stage_end(ST_FIRST, s);
+    }
     launch_gather_rows(hidden_all_, S, H, idx_a_, idx_b_, B, l_xlast_, s);
     GemvArgs h;
     h.x = l_xlast_; h.ldx = H; gemv_w(h, lm_head_); h.y = l_logits_; h.ldy = c.llm_vocab; h.B = B; h.N = c.llm_vocab;

@@ -138,6 +138,7 @@ void Stamper::enable(bool want) {
     eager_.clear();
     epoch_keys_.clear();
     eager_used_ = 0;
+    dropped_ = 0;
   }
   on = want;
 }
@@ -146,7 +147,10 @@ StampArgs Stamper::slot(const char* tag, double bytes, int grid) {
   if (!on || !buf_) return a;
   const size_t need = (size_t)grid * 2;
   if (capturing_ >= 0) {
-    if (cap_used_ + need > graph_stride_) return a;  // step larger than the record: this launch goes unstamped
+    if (cap_used_ + need > graph_stride_) {  // step larger than the record: this launch goes unstamped (and is counted)
+      ++dropped_;
+      return a;
+    }
     graphs_[capturing_].push_back({tag, bytes, grid, cap_used_});
     a.base = buf_ + graph_off_ + cap_used_;
     a.epoch = ctl_;
@@ -154,7 +158,10 @@ StampArgs Stamper::slot(const char* tag, double bytes, int grid) {
     a.max_epoch = max_epoch_;
     cap_used_ += need;
   } else {
-    if (eager_used_ + need > eager_cap_) return a;
+    if (eager_used_ + need > eager_cap_) {
+      ++dropped_;
+      return a;
+    }
     eager_.push_back({tag, bytes, grid, eager_used_});
     a.base = buf_ + eager_used_;
     a.epoch = ctl_ + 1;
@@ -172,6 +179,11 @@ void Stamper::graph_begin(int key) {
 void Stamper::graph_end(hipStream_t cap) {
   hipLaunchKernelGGL(stamp_bump_kernel, dim3(1), dim3(1), 0, cap, ctl_);
   capturing_ = -1;
+}
+void Stamper::graph_abort() {
+  if (capturing_ >= 0) graphs_.erase(capturing_);
+  capturing_ = -1;
+  cap_used_ = 0;
 }
 std::vector<StampRow> Stamper::collect() {
   std::vector<StampRow> rows;
@@ -222,6 +234,7 @@ std::vector<StampRow> Stamper::collect() {
   eager_.clear();
   epoch_keys_.clear();
   eager_used_ = 0;
+  dropped_ = 0;
   return rows;
 }
 

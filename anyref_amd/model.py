@@ -382,6 +382,8 @@ class AnyRefForCausalLM:
         """-> [dict(tag, t0_us, t1_us, bytes, epoch)] of every stamped launch since enable / the last read, by start time."""
         torch.cuda.synchronize(self.device)
         n = _lib._L()
+        self._check(self.lib.anyref_stamps_dropped(self.h, C.byref(n)), "stamps_dropped")
+        self.stamps_dropped = int(n.value)      # launches of this pass that went unstamped (record / epoch capacity): 0 or the rows lie
         self._check(self.lib.anyref_stamps_collect(self.h, C.byref(n)), "stamps_collect")
         name = C.create_string_buffer(128)
         t0, t1, by, ep = C.c_double(), C.c_double(), C.c_double(), C.c_int()

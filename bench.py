@@ -253,6 +253,9 @@ def main():
                 step()
             rows = model.stamps_read()
             model.stamps_enable(False)
+            # a pass longer than the stamp record (48 graph replays, 256 launches x 512 workgroups per step) would silently
+            # drop launches while the per-step figures still divide by `n`
+            assert model.stamps_dropped == 0, f"{model.stamps_dropped} launches went unstamped: lower --roofline-steps / --max-new-tokens"
             return rows
 
         def by_tag(rows):
@@ -267,6 +270,7 @@ def main():
         roofline = None
         # (every rank runs the same passes whatever it finds dominant: the steps contain collectives)
         rows, iso_rows = [], []
+        roofline_steps = min(roofline_steps, max(1, 48 // max(1, T - 1)))     # graph replays per pass <= the stamp record's epochs
         if roofline_steps > 0:
             rows = stamp_pass(roofline_steps)
             model.set_overlap(False)

@@ -254,6 +254,10 @@ int anyref_profile_read(anyref_handle* h, int idx, char* name, int cap, double* 
  */
 int anyref_stamps_enable(anyref_handle* h, int on);
 int anyref_stamps_collect(anyref_handle* h, int64_t* count);
+/* launches that went UNSTAMPED since enable / the last collect -- a step larger than the per-step record, or graph replays past
+ * the epoch capacity (48): read it BEFORE anyref_stamps_collect (which resets it); non-zero means per-step averages built on the
+ * collected rows miss launches */
+int anyref_stamps_dropped(anyref_handle* h, int64_t* count);
 int anyref_stamps_read(anyref_handle* h, int64_t idx, char* name, int cap, double* t0_us, double* t1_us,
                        double* bytes, int* epoch);
 /* the same launch's spread over its workgroups: last start - first start (dispatch ramp), last end - first end (tail),

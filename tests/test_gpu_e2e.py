@@ -443,7 +443,8 @@ def test_raw_mel_audio_through_imagebind_on_the_gpu():
     assert (masks2[0].cpu() - ref["pred_masks"][0]).abs().max().item() <= MASK_TOL
 
 
-def test_side_stream_cu_share_is_bit_identical():
+@pytest.mark.parametrize("mode", ["perf", "parity16"])
+def test_side_stream_cu_share_is_bit_identical(mode):
     """`anyref_set_side_share`: the SAM encoder's GEMM / attention launches capped at n workgroups (walking kernels for
     the 128-row tiles and the global attention, row-block / window-group launches for the 256-row tiles and the 13-wave
     window attention) and its blocks queued a few per decode step -- same ids, hidden states and masks bit for bit as the
@@ -460,7 +461,7 @@ def test_side_stream_cu_share_is_bit_identical():
     sam = torch.randn(1, 3, 1024, 1024, generator=g)
     ids = torch.cat([torch.tensor([1, IMAGE_TOKEN_INDEX]), torch.randint(3, 990, (14,), generator=g)])[None]
     sizes, H, W = [(1024, 1024)], [1024], [1024]
-    m = AnyRefForCausalLM.from_state_dict(cfg, {k: v.cuda() for k, v in sd.items()}, mode="perf", max_batch=1, max_seg=4)
+    m = AnyRefForCausalLM.from_state_dict(cfg, {k: v.cuda() for k, v in sd.items()}, mode=mode, max_batch=1, max_seg=4)
     m.config.eos_token_id = None
     m.set_side_share(0)
     o0, _, _ = m.generate(clip, ids, sam, sizes, H, W, max_new_tokens=8)
