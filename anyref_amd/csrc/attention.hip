@@ -890,7 +890,7 @@ __device__ __forceinline__ void attn_sp_body(const AttnArgs& a, const int bx, co
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int qi = lane & 15, g = lane >> 4;
-  const int b = bz, h = by, q0 = bx * BQ;
+  const int b = bz, h = by + a.h_off, q0 = bx * BQ;
   const int kv_len = a.kv_len ? a.kv_len[b] : a.Sk;
   const int q_len = a.q_len ? a.q_len[b] : a.Sq;
   if (q0 >= q_len) return;  // uniform per workgroup
@@ -936,8 +936,9 @@ __device__ __forceinline__ void attn_sp_body(const AttnArgs& a, const int bx, co
       relw_s[i] = q0 + r < q_len ? P[(int64_t)r * a.rel_ld + np + (x - c + a.kw - 1)] * LOG2E : 0.f;
     }
   } else if (has_rel) {
-    const float* rh = a.rel_h + ((int64_t)b * a.H + h) * a.Sq * a.kh;
-    const float* rw = a.rel_w + ((int64_t)b * a.H + h) * a.Sq * a.kw;
+    const int Hall = a.h_total > 0 ? a.h_total : a.H;
+    const float* rh = a.rel_h + ((int64_t)b * Hall + h) * a.Sq * a.kh;
+    const float* rw = a.rel_w + ((int64_t)b * Hall + h) * a.Sq * a.kw;
     for (int i = tid; i < BQ * a.kh; i += NT) {
       const int r = i / a.kh, c = i % a.kh;
       relh_s[i] = q0 + r < q_len ? rh[(int64_t)(q0 + r) * a.kh + c] * LOG2E : 0.f;
@@ -1139,7 +1140,33 @@ static void attn_sp_launch_cfg(const AttnArgs& a, hipStream_t s) {
   const double flops = 4.0 * a.B * a.H * (double)a.Sq * a.Sk * HD * (a.causal ? 0.5 : 1.0);
   const double bytes = (double)a.B * a.H * HD * 4.0 * (2.0 * a.Sq + 2.0 * a.Sk);
   ProfScope prof(tag.c_str(), flops, bytes, s);
-  hipLaunchKernelGGL(kern, dim3(cdiv(a.Sq, BQ), a.H, a.B), dim3(NWV * 64), lds, s, a);
+  const int gx = cdiv(a.Sq, BQ);
+  if (a.max_wg > 0 && (int64_t)gx * a.H * a.B > a.max_wg) {
+    // CU share of the side stream (the SAM encoder beside the decode loop): the launch is cut into groups of batch items
+    // (windows) or, where one item alone exceeds the cap (global attention: 32 query blocks x 16 heads), groups of heads
+    const int per_b = std::max(1, a.max_wg / (gx * a.H)), per_h = gx * a.H > a.max_wg ? std::max(1, a.max_wg / gx) : a.H;
+    for (int b0 = 0; b0 < a.B; b0 += per_b)
+      for (int h0 = 0; h0 < a.H; h0 += per_h) {
+        AttnArgs c = a;
+        c.B = std::min(per_b, a.B - b0);
+        c.H = std::min(per_h, a.H - h0);
+        c.h_off = h0;
+        c.h_total = a.H;
+        c.Q = reinterpret_cast<const float*>(a.Q) + (int64_t)b0 * a.q_bs;
+        c.K = reinterpret_cast<const float*>(a.K) + (int64_t)b0 * a.k_bs;
+        c.V = reinterpret_cast<const float*>(a.V) + (int64_t)b0 * a.v_bs;
+        c.O = a.o_split ? (void*)(reinterpret_cast<sp16*>(a.O) + (int64_t)b0 * a.o_bs) : (void*)(reinterpret_cast<float*>(a.O) + (int64_t)b0 * a.o_bs);
+        if (a.rel_p) c.rel_p = a.rel_p + (int64_t)b0 * a.Sq * a.rel_ld;
+        if (a.rel_h) c.rel_h = a.rel_h + (int64_t)b0 * a.H * a.Sq * a.kh;
+        if (a.rel_w) c.rel_w = a.rel_w + (int64_t)b0 * a.H * a.Sq * a.kw;
+        if (a.q_len) c.q_len = a.q_len + b0;
+        if (a.kv_len) c.kv_len = a.kv_len + b0;
+        if (a.q_pos0) c.q_pos0 = a.q_pos0 + b0;
+        hipLaunchKernelGGL(kern, dim3(gx, c.H, c.B), dim3(NWV * 64), lds, s, c);
+      }
+    return;
+  }
+  hipLaunchKernelGGL(kern, dim3(gx, a.H, a.B), dim3(NWV * 64), lds, s, a);
 }
 // whether launch_attention<float> takes the split-pair kernel for this call (AttnArgs::sp16 set by the caller)
 static bool attn_sp_takes(const AttnArgs& a) {

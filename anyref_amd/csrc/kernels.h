@@ -270,6 +270,9 @@ struct AttnArgs {
   // 1 (T = float only, head dim 64 / 80 / 128): the f32 operands are multiplied as bf16 PAIRS on the 16-bit MFMA (three
   // passes per product, attention.hip attn_sp_body) instead of the f32 MFMA -- same f32-level result at 3/16 of the MFMA time
   int sp16 = 0;
+  // split-pair kernel, set by its launcher when a capped launch is cut into head groups: this launch covers heads h_off ..
+  // h_off + H - 1 of h_total (0: H) heads -- strides and the rel_h / rel_w arrays span all of them
+  int h_off = 0, h_total = 0;
   int max_wg = 0;  // > 0: at most this many workgroups (bf16, head dim 80, the SAM forms); each walks several blocks
   // set by the launcher: keys split over kv_splits workgroups per query block, partials merged afterwards
   int kv_splits = 1;
