@@ -20,7 +20,7 @@ from anyref_amd.synth import synth_state_dict  # noqa: E402
 from oracle import anyref_oracle as O  # noqa: E402
 
 # |emb| = 20 per row.  parity (f32): measured 3.8e-6 vs the reference; perf (bf16 trunk): measured 1.6e-2, bound = 2 x
-TOL = {"parity": 1e-3, "perf": 0.035}
+TOL = {"parity": 1e-3, "parity16": 1e-3, "perf": 0.035}
 
 
 def _with_trunk(sd, trunk):
@@ -30,11 +30,17 @@ def _with_trunk(sd, trunk):
     return sd
 
 
-@pytest.mark.parametrize("mode", ["parity", "perf"])
+@pytest.mark.parametrize("mode", ["parity", "parity16", "perf"])
 def test_audio_trunk_real_size_vs_reference_fixture(mode):
     from anyref_amd.model import AnyRefForCausalLM
     fx = np.load(os.path.join(HERE, "golden", "imagebind_audio.npz"))
     trunk = ga.seeded_audio_module()                       # the weights the reference ran with
+    if mode == "parity16":
+        # parity16 multiplies weights in their exact bf16 storage: the fixture's f32 trunk weights are rounded to bf16 once, on
+        # both sides (as the synthetic workloads are); what is held to 1e-3 is then the arithmetic, against the torch module
+        with torch.no_grad():
+            for prm in trunk.parameters():
+                prm.copy_(prm.to(torch.bfloat16).float())
     mel = ga.audio_inputs()
     cfg = config_tiny()
     sd = _with_trunk(synth_state_dict(cfg, seed=3, scale=0.05), trunk)
@@ -47,7 +53,7 @@ def test_audio_trunk_real_size_vs_reference_fixture(mode):
     _, want = trunk.get_audio_feature(mel)
     e_torch = float((emb - want[0]).abs().max())
     print(f"[{mode}] HIP audio trunk: max-abs-err vs the reference's output {e_ref:.3e}, vs the torch module {e_torch:.3e} (|emb| = 20)")
-    assert e_ref <= TOL[mode] and e_torch <= TOL[mode]
+    assert (mode == "parity16" or e_ref <= TOL[mode]) and e_torch <= TOL[mode]   # (parity16: e_ref includes the weight rounding)
     with pytest.raises(RuntimeError, match="too many clips"):
         m.audio_encode(torch.zeros(4, 1, 128, 204))
 
@@ -85,7 +91,7 @@ def test_generate_with_raw_mel_through_the_hip_trunk():
     assert (masks[0].cpu() - ref["pred_masks"][0]).abs().max().item() <= 1e-3
 
 
-@pytest.mark.parametrize("mode", ["parity", "perf"])
+@pytest.mark.parametrize("mode", ["parity", "parity16", "perf"])
 def test_c4_full_width_raw_mel_through_the_hip_trunk_vs_oracle(mode):
     """BASELINE configs[3] at FULL WIDTH, reduced depth: 1024^2 SAM-H-width encoder (1280 wide, 16 heads of 80, one
     14-window + one global block), CLIP ViT-L width (3 layers), two LLaMA-7B-width decoder layers, and the ImageBind
@@ -130,7 +136,7 @@ def test_c4_full_width_raw_mel_through_the_hip_trunk_vs_oracle(mode):
     print(f"C4_FULL_WIDTH[{mode}] trunk max-abs-err {e_trunk:.3e} (|emb| = 20) " +
           " ".join(f"{k}={v:.3e}" if isinstance(v, float) else f"{k}={v}" for k, v in r.items()))
     assert e_trunk <= TOL[mode]
-    if mode == "parity":
+    if mode in ("parity", "parity16"):       # north_star's bar, for the pure-f32 mode and for the bf16-pair mode alike
         assert r["greedy_ids_identical"], r
         assert r["mask_logit_max_abs_err"] <= 1e-3, r
     else:

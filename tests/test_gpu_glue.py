@@ -19,7 +19,7 @@ from anyref_amd.synth import synth_state_dict  # noqa: E402
 GLUE = np.load(os.path.join(HERE, "golden", "glue_anyref.npz"))
 # the hand-off and the whole mask decoder are f32 in both modes; only the SAM image encoder differs (bf16 in perf):
 # measured 8e-7 (parity) / 1.6e-3 (perf) on MI355X -> bound = the 1e-3 north-star bar / 2 x measured
-TOL = {"parity": 1e-3, "perf": 3.2e-3}
+TOL = {"parity": 1e-3, "parity16": 1e-3, "perf": 3.2e-3}
 
 
 def _model(c, mode, seg_list=False):
@@ -31,7 +31,7 @@ def _model(c, mode, seg_list=False):
     return AnyRefForCausalLM.from_state_dict(cfg, {k: v.cuda() for k, v in sd.items()}, mode=mode, max_batch=2, max_seg=3)
 
 
-@pytest.mark.parametrize("mode", ["parity", "perf"])
+@pytest.mark.parametrize("mode", ["parity", "perf"])     # (parity16 needs 64-multiple widths: this fixture's CLIP is 32 wide)
 @pytest.mark.parametrize("name", list(gg.GEN_CASES))
 def test_generate_tail_vs_reference(name, mode):
     x = gg.case_inputs(name)
