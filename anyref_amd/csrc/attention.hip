@@ -921,8 +921,60 @@ __device__ __forceinline__ void attn_sp_body(const AttnArgs& a, const int bx, co
     }
   }
   constexpr float LOG2E = 1.4426950408889634f;
-  const bool has_rel = a.rel_h != nullptr || a.rel_p != nullptr;
-  if (a.rel_p) {
+  // f32 rel-pos TABLES (the windows, 2 k - 1 <= 32 entries): the bias rows of this block's queries are computed here -- R q^T on
+  // the 16-bit MFMA with BOTH sides as bf16 pairs (Rl qh + Rh ql + Rh qh, the q fragments this wave already holds), then the
+  // reference's shifted gather (get_rel_pos, image_encoder.py:321-392) as a scatter, exactly as the 16-bit resident-key kernel
+  // does it.  Replaces the f32-MFMA rel-pos GEMM launch (40 us per layer at SAM-H) and its 17 MB P buffer round trip.
+  const bool rel_tab = a.rel_tab_h != nullptr;
+  const bool has_rel = a.rel_h != nullptr || a.rel_p != nullptr || rel_tab;
+  if (rel_tab) {
+    bf16* Rs = reinterpret_cast<bf16*>(relw_s + BQ * a.kw);  // [table][hi | lo][32][LDK], zero padded
+    for (int i = tid; i < BQ * (a.kh + a.kw); i += NT) relh_s[i] = 0.f;  // (relw_s follows relh_s)
+    constexpr int RV = LDK / VEC;
+    for (int i = tid; i < 2 * 32 * RV; i += NT) {
+      const int t = i / (32 * RV), e = (i / RV) % 32, d = (i % RV) * VEC;
+      const int ne = 2 * (t == 0 ? a.kh : a.kw) - 1;
+      const float* tab = reinterpret_cast<const float*>(t == 0 ? a.rel_tab_h : a.rel_tab_w) + (int64_t)e * a.rel_tab_ld + d;
+      float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (e < ne && d < HD) {
+        const float4v x0 = *reinterpret_cast<const float4v*>(tab), x1 = *reinterpret_cast<const float4v*>(tab + 4);
+        f[0] = x0[0]; f[1] = x0[1]; f[2] = x0[2]; f[3] = x0[3]; f[4] = x1[0]; f[5] = x1[1]; f[6] = x1[2]; f[7] = x1[3];
+      }
+      short8 hi, lo;
+      split8(f, hi, lo);
+      *reinterpret_cast<short8*>(&Rs[((t * 2 + 0) * 32 + e) * LDK + d]) = hi;
+      *reinterpret_cast<short8*>(&Rs[((t * 2 + 1) * 32 + e) * LDK + d]) = lo;
+    }
+    __syncthreads();
+    float4v pb[2][2];  // [table][entry block]: P^T[entry 16 blk + 4 g + r][this lane's query]
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk) {
+        pb[t][blk] = float4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < HDK / KS; ++kk) {
+          const short8 rh = *reinterpret_cast<const short8*>(&Rs[((t * 2 + 0) * 32 + blk * 16 + qi) * LDK + kk * KS + 8 * g]);
+          const short8 rl = *reinterpret_cast<const short8*>(&Rs[((t * 2 + 1) * 32 + blk * 16 + qi) * LDK + kk * KS + 8 * g]);
+          pb[t][blk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rl, qh[kk], pb[t][blk], 0, 0, 0);  // small terms first
+          pb[t][blk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rh, ql[kk], pb[t][blk], 0, 0, 0);
+          pb[t][blk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rh, qh[kk], pb[t][blk], 0, 0, 0);
+        }
+      }
+    if (q_ok) {
+      const int y = iq / a.kw, x = iq - y * a.kw;
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int e = blk * 16 + 4 * g + r;
+          const int ch = y + a.kh - 1 - e, cw = x + a.kw - 1 - e;
+          if (ch >= 0 && ch < a.kh) relh_s[il * a.kh + ch] = pb[0][blk][r] * LOG2E;
+          if (cw >= 0 && cw < a.kw) relw_s[il * a.kw + cw] = pb[1][blk][r] * LOG2E;
+        }
+    }
+    // (the barrier in front of the first key tile orders these stores before any bias read)
+  } else if (a.rel_p) {
     const float* P = a.rel_p + (int64_t)h * a.rel_hs + ((int64_t)b * a.Sq + q0) * a.rel_ld;
     const int np = a.rel_ld / 2;
     for (int i = tid; i < BQ * a.kh; i += NT) {
@@ -1131,7 +1183,13 @@ template <int HD, int NWV, int BKV>
 static void attn_sp_launch_cfg(const AttnArgs& a, hipStream_t s) {
   constexpr int BQ = 16 * NWV, HDK = (HD + 31) / 32 * 32, LDK = HDK + 8, LDV = ((HD * 2 + 255) / 256 * 256 + 32) / 2;
   size_t lds = 2 * 2 * (size_t)(BKV * LDK + BKV * LDV);
-  if (a.rel_h || a.rel_p) lds += sizeof(float) * BQ * (a.kh + a.kw);
+  if (a.rel_h || a.rel_p || a.rel_tab_h) lds += sizeof(float) * BQ * (a.kh + a.kw);
+  if (a.rel_tab_h) {
+    if (2 * a.kh - 1 > 32 || 2 * a.kw - 1 > 32 || a.Sq != a.kh * a.kw || a.rel_tab_ld % 4 || ((uintptr_t)a.rel_tab_h & 15) ||
+        ((uintptr_t)a.rel_tab_w & 15))
+      throw std::runtime_error("split-pair attention: rel-pos tables need k <= 16, Sq == kh * kw and 16-byte aligned f32 rows");
+    lds += 2 * 2 * 2 * 32 * (size_t)LDK;  // two tables x (hi, lo) x 32 entries, bf16
+  }
   if (lds > 160 * 1024) throw std::runtime_error("split-pair attention: LDS budget exceeded");
   auto kern = &attn_sp_kernel<HD, NWV, BKV>;
   static KernelAttrOnce once;
@@ -1172,7 +1230,8 @@ static void attn_sp_launch_cfg(const AttnArgs& a, hipStream_t s) {
 static bool attn_sp_takes(const AttnArgs& a) {
   static const bool off = getenv("ANYREF_NO_SP16_ATTN") != nullptr;  // lab knob: the f32-MFMA kernel instead
   if (off || !a.sp16 || (a.hd != 64 && a.hd != 80 && a.hd != 128)) return false;
-  if (a.rel_tab_h || (a.o_f32 && a.o_split)) return false;
+  if (a.o_f32 && a.o_split) return false;
+  if (a.rel_tab_h && !attention_takes_rel_tables(4, a.hd, a.Sq, a.Sk, a.kh, a.kw, true)) return false;
   if ((a.rel_h || a.rel_p) && (a.kw > 64 || a.kh * a.kw > 4096)) return false;  // (the multiply-shift j / kw)
   if (a.o_rs % 4 || a.o_hs % 4 || a.o_bs % 4 || ((uintptr_t)a.O & 15)) return false;
   return true;
@@ -1426,7 +1485,9 @@ static void attn_launch(const AttnArgs& a, hipStream_t s) {
   attn_launch_cfg<T, HD, 4, 0>(a, s);
 }
 
-bool attention_takes_rel_tables(int elem_bytes, int hd, int Sq, int Sk, int kh, int kw) {
+bool attention_takes_rel_tables(int elem_bytes, int hd, int Sq, int Sk, int kh, int kw, bool split) {
+  // split: f32 operands multiplied as bf16 pairs (ANYREF_MODE_PARITY16), f32 tables: attn_sp_kernel, any block of a kh x kw window
+  if (split) return elem_bytes == 4 && (hd == 64 || hd == 80 || hd == 128) && Sq == Sk && Sq == kh * kw && kh <= 16 && kw <= 16;
   return elem_bytes == 2 && hd == 80 && Sq == Sk && Sq > 192 && Sq <= 208 && kh <= 16 && kw <= 16;  // = attn_launch
 }
 

@@ -283,7 +283,7 @@ template <typename T>
 void launch_attention(const AttnArgs& a, hipStream_t s);
 // whether launch_attention<T> runs this (non-causal, full-length) shape in the resident-key form, which takes the
 // rel-pos TABLES (rel_tab_*) instead of a precomputed P
-bool attention_takes_rel_tables(int elem_bytes, int hd, int Sq, int Sk, int kh, int kw);
+bool attention_takes_rel_tables(int elem_bytes, int hd, int Sq, int Sk, int kh, int kw, bool split = false);
 
 // Decode-step attention for ONE new token per sequence, fused with RoPE and the KV-cache append:
 // qkv f32 [B,3*H*hd] (this step's projections) -> rotates q,k at pos[b], appends k,v to the cache,
@@ -342,10 +342,11 @@ void launch_scatter_rows(const float* rows, const int* dst_b, const int* dst_pos
 // RoPE (rotate_half form) on q,k of a fused qkv buffer + append k,v to the cache.
 // qkv T [B,S,3,H,hd]; pos0 i32 [B] dev; q_out T [B,S,H,hd]; kc/vc T [B,maxS,H,hd];
 // cs_tab f32 [maxS][2][hd/2] = cos | sin of pos * inv_freq (built on the host like HF does)
-// same from two f32 split-K slices of the projection (slab0 + slab1, rounded to bf16 first like the GEMM's own output)
+// same from two f32 split-K slices of the projection (slab0 + slab1, rounded to bf16 first like the GEMM's own output);
+// out_f32: q_out / kc / vc / q_keep are f32 and the sum is not rounded (ANYREF_MODE_PARITY16)
 void launch_rope_cache_slabs(const float* slab0, const float* slab1, int B, int S, int H, int hd, const int* pos0,
                              const int* lens, const float* cs_tab, void* q_out, void* kc, void* vc, int maxS, void* q_keep,
-                             hipStream_t s);
+                             hipStream_t s, bool out_f32 = false);
 template <typename T>
 void launch_rope_cache(const void* qkv, int B, int S, int H, int hd, const int* pos0, const int* lens,
                        const float* cs_tab, void* q_out, void* kc, void* vc, int maxS, void* q_keep,

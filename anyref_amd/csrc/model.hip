@@ -779,7 +779,7 @@ void Model<T, TS>::finalize() {
     hidden_all_ = talloc<float>(R * H);
     l_h_ = aalloc<T>(R, std::max(H, c.audio_dim));  // (project_audio stages its input rows here)
     l_qkv_ = talloc<Q>(R * 3 * H);
-    if (sizeof(T) == 2 && (size_t)3 * H / 96 * 2 <= 256) qkv_slabs_ = talloc<float>((size_t)2 * 320 * 3 * H);  // prefill qkv K slices (R <= 320)
+    if ((sizeof(T) == 2 || SPT) && (size_t)3 * H / 96 * 2 <= 256) qkv_slabs_ = talloc<float>((size_t)2 * 320 * 3 * H);  // prefill qkv K slices (R <= 320)
     l_q_ = talloc<Q>(R * H);
     l_att_ = aalloc<T>(R, H);
     l_act_ = aalloc<T>(R, F);
@@ -1308,7 +1308,7 @@ void Model<T, TS>::llm_prefill(hipStream_t s, int B, int Sp, const int* lens_dev
       a.slabs_out = qkv_slabs_; a.slabs = 2;
       launch_gemm<T>(a, s);
       launch_rope_cache_slabs(qkv_slabs_, qkv_slabs_ + (size_t)R * 3 * H, B, Sp, nh, hd, nullptr, lens_dev, rope_tab_, l_q_, kc,
-                              vc, S, qkeep, s);
+                              vc, S, qkeep, s, QF32);
     } else {
       gemm(s, l_h_, H, L.qkv, l_qkv_, 3 * H, R, ACT_NONE, QF32);
       launch_rope_cache<Q>(l_qkv_, B, Sp, nh, hd, nullptr, lens_dev, rope_tab_, l_q_, kc, vc, S, qkeep, s);
@@ -1501,7 +1501,7 @@ void Model<T, TS>::sam_encoder(hipStream_t s, const float* images, int B, float*
       }
       gemm(s, s_hglob_, D, L.qkv, s_qkv_, 3 * D, RT, ACT_NONE, QF32S, nullptr, 0, tok2win_);
       if (!filled) launch_fill_rows_bias<QS>(s_qkv_, 3 * D, pad_rows_, n_pad_rows_ * B, L.qkv.b, 3 * D, s);
-      if (attention_takes_rel_tables((int)sizeof(TS), hd, S2, S2, ws, ws)) {
+      if (attention_takes_rel_tables((int)sizeof(QS), hd, S2, S2, ws, ws, SPS)) {  // (16-bit towers: sizeof(QS) == sizeof(TS))
         // window bias straight from the tables inside the attention kernel (rows 0.. = rel_pos_h, Np.. = rel_pos_w)
         a.rel_tab_h = L.rel.w; a.rel_tab_w = L.rel.w + (size_t)(L.rel.n / 2) * L.rel.k; a.rel_tab_ld = L.rel.k;
       } else {

@@ -836,12 +836,60 @@ void launch_rope_cache(const void* qkv, int B, int S, int H, int hd, const int* 
                      S, H, hd, pos0, lens, cs_tab, reinterpret_cast<T*>(q_out), reinterpret_cast<T*>(kc),
                      reinterpret_cast<T*>(vc), maxS, reinterpret_cast<T*>(q_keep));
 }
+// f32 q / k / v (ANYREF_MODE_PARITY16: f32 attention operands and KV cache) from the two f32 K slices of the projection: a lane
+// takes 4 consecutive d of the first half and their partners, 16-byte accesses; the rotation in the scalar kernel's f32 order
+__global__ __launch_bounds__(256) void rope_cache_slabs_f32_kernel(const float* __restrict__ slab0, const float* __restrict__ slab1,
+                                                                   int S, int H, int hd, const int* __restrict__ pos0,
+                                                                   const int* __restrict__ lens, const float* __restrict__ cs_tab,
+                                                                   float* __restrict__ q_out, float* __restrict__ kc,
+                                                                   float* __restrict__ vc, int maxS, float* __restrict__ q_keep) {
+  const int srow = blockIdx.x, b = blockIdx.y;
+  if (lens && srow >= lens[b]) return;
+  const int pos = (pos0 ? pos0[b] : 0) + srow;
+  const int half = hd / 2, per = half / 4;  // lanes per head
+  const int64_t roff = ((int64_t)b * S + srow) * 3 * H * hd;
+  auto ld4 = [&](int c) { return *reinterpret_cast<const float4v*>(slab0 + roff + c) + *reinterpret_cast<const float4v*>(slab1 + roff + c); };
+  for (int i = threadIdx.x; i < H * per; i += blockDim.x) {
+    const int h = i / per, d = (i % per) * 4;
+    const float4v cs = *reinterpret_cast<const float4v*>(cs_tab + ((int64_t)pos * 2) * half + d);
+    const float4v sn = *reinterpret_cast<const float4v*>(cs_tab + ((int64_t)pos * 2 + 1) * half + d);
+    const float4v q1 = ld4(h * hd + d), q2 = ld4(h * hd + d + half);
+    const float4v k1 = ld4((H + h) * hd + d), k2 = ld4((H + h) * hd + d + half);
+    const float4v v1 = ld4((2 * H + h) * hd + d), v2 = ld4((2 * H + h) * hd + d + half);
+    float4v qa, qb, ka, kb;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      qa[e] = q1[e] * cs[e] - q2[e] * sn[e];
+      qb[e] = q2[e] * cs[e] + q1[e] * sn[e];
+      ka[e] = k1[e] * cs[e] - k2[e] * sn[e];
+      kb[e] = k2[e] * cs[e] + k1[e] * sn[e];
+    }
+    float* qo = q_out + (((int64_t)b * S + srow) * H + h) * hd;
+    *reinterpret_cast<float4v*>(qo + d) = qa;
+    *reinterpret_cast<float4v*>(qo + d + half) = qb;
+    const int64_t co = (((int64_t)b * maxS + pos) * H + h) * hd;
+    if (q_keep) {
+      *reinterpret_cast<float4v*>(q_keep + co + d) = qa;
+      *reinterpret_cast<float4v*>(q_keep + co + d + half) = qb;
+    }
+    *reinterpret_cast<float4v*>(kc + co + d) = ka;
+    *reinterpret_cast<float4v*>(kc + co + d + half) = kb;
+    *reinterpret_cast<float4v*>(vc + co + d) = v1;
+    *reinterpret_cast<float4v*>(vc + co + d + half) = v2;
+  }
+}
 void launch_rope_cache_slabs(const float* slab0, const float* slab1, int B, int S, int H, int hd, const int* pos0,
                              const int* lens, const float* cs_tab, void* q_out, void* kc, void* vc, int maxS, void* q_keep,
-                             hipStream_t s) {
+                             hipStream_t s, bool out_f32) {
   if (hd % 16 || (((uintptr_t)slab0 | (uintptr_t)slab1 | (uintptr_t)q_out | (uintptr_t)kc | (uintptr_t)vc | (uintptr_t)q_keep |
                    (uintptr_t)cs_tab) & 15))
     throw std::runtime_error("rope_cache_slabs: head dim % 16 and 16-byte aligned buffers");
+  if (out_f32) {
+    hipLaunchKernelGGL(rope_cache_slabs_f32_kernel, dim3(S, B), dim3(256), 0, s, slab0, slab1, S, H, hd, pos0, lens, cs_tab,
+                       reinterpret_cast<float*>(q_out), reinterpret_cast<float*>(kc), reinterpret_cast<float*>(vc), maxS,
+                       reinterpret_cast<float*>(q_keep));
+    return;
+  }
   hipLaunchKernelGGL(rope_cache_vec_kernel<true>, dim3(S, B), dim3(256), 0, s, (const bf16*)nullptr, slab0, slab1, S, H, hd,
                      pos0, lens, cs_tab, reinterpret_cast<bf16*>(q_out), reinterpret_cast<bf16*>(kc),
                      reinterpret_cast<bf16*>(vc), maxS, reinterpret_cast<bf16*>(q_keep));

@@ -136,6 +136,14 @@ int anyref_op_attention_tab(int t, void* stream, const void* q, const void* k, c
     a.q_rs = a.k_rs = a.v_rs = a.o_rs = H * hd; a.q_hs = a.k_hs = a.v_hs = a.o_hs = hd;
     a.B = B; a.H = H; a.Sq = S; a.Sk = S; a.hd = hd; a.scale = scale;
     a.rel_tab_h = tab_h; a.rel_tab_w = tab_w; a.rel_tab_ld = tab_ld; a.kh = kh; a.kw = kw;
+    if (t == 3) {  // split-pair attention: f32 operands and f32 tables, pair-typed output rows; o gets hi + lo
+      if ((H * hd) % 64) throw std::runtime_error("op_attention_tab t=3: H * hd % 64 != 0");
+      if (!attention_takes_rel_tables(4, hd, S, S, kh, kw, true)) throw std::runtime_error("op_attention_tab t=3: not a window shape");
+      TmpBuf Os((size_t)B * S * H * hd * 4);
+      a.O = Os.p; a.o_split = 1; a.sp16 = 1;
+      launch_attention<float>(a, (hipStream_t)stream);
+      launch_unsplit(Os.p, H * hd, reinterpret_cast<float*>(o), H * hd, B * S, H * hd, (hipStream_t)stream);
+    } else
     if (t == 2) launch_attention<f16>(a, (hipStream_t)stream);
     else launch_attention<bf16>(a, (hipStream_t)stream);
   });

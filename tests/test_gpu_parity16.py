@@ -196,6 +196,44 @@ def test_split_pair_attention_with_rel_pos_bias(lib, B, H, size):
     close(o, ref, 2e-5, f"rel-pos attention size {size}")
 
 
+@pytest.mark.parametrize("B,H,size,hd", [(1, 4, 14, 80), (5, 4, 14, 80), (2, 2, 4, 64), (3, 1, 16, 128)])
+def test_split_pair_window_attention_bias_from_tables(lib, B, H, size, hd):
+    """SAM windows as parity16 runs them since the P buffer went away: the split-pair kernel computes q . R^T itself from the
+    f32 rel-pos tables (both sides as bf16 pairs) and applies the get_rel_pos shift as a scatter (image_encoder.py:321-392);
+    14 x 14 = two query blocks of 112, 4 x 4 / 16 x 16 = the tiny configs' windows.  Also: the same call through the P-buffer
+    path of the same kernel (only the bias differs in its summation), and the refusal of a non-window shape."""
+    from test_gpu_ops import ref_attention
+    ld = 128
+    g = torch.Generator().manual_seed(B * 13 + H + size)
+    S = size * size
+    q, k, v = (torch.randn(B, S, H, hd, generator=g) for _ in range(3))
+    th, tw = torch.randn(2 * size - 1, hd, generator=g) * 0.3, torch.randn(2 * size - 1, hd, generator=g) * 0.3
+    idx = torch.arange(size)[:, None] - torch.arange(size)[None, :] + size - 1
+    rq = q.double().permute(0, 2, 1, 3).reshape(B, H, size, size, hd)
+    rel_h = torch.einsum("bnhwc,hkc->bnhwk", rq, th.double()[idx]).reshape(B, H, S, size)
+    rel_w = torch.einsum("bnhwc,wkc->bnhwk", rq, tw.double()[idx]).reshape(B, H, S, size)
+    scale = hd ** -0.5
+    ref = ref_attention(q.double(), k.double(), v.double(), scale, False, None, rel_h, rel_w, size)
+    tab = torch.zeros(2, 2 * size, ld)                      # padded rows / columns as the model packs them
+    tab[0, : 2 * size - 1, :hd], tab[1, : 2 * size - 1, :hd] = th, tw
+    tab = tab.cuda()
+    o = torch.empty(B, S, H, hd, device="cuda")
+    check(lib, lib.anyref_op_attention_tab(SP, None, P(q.cuda()), P(k.cuda()), P(v.cuda()), P(o), B, H, S, hd, scale,
+                                           P(tab[0]), P(tab[1]), ld, size, size))
+    close(o, ref, 2e-5, f"window attention from tables, size {size} hd {hd}")
+    npad = 2 * size
+    p = torch.zeros(H, B * S, 2 * npad, dtype=torch.float64)
+    qh = q.double().permute(2, 0, 1, 3).reshape(H, B * S, hd)
+    p[:, :, : 2 * size - 1] = qh @ th.double().t()
+    p[:, :, npad: npad + 2 * size - 1] = qh @ tw.double().t()
+    o2 = torch.empty_like(o)
+    check(lib, lib.anyref_op_attention_relp(SP, None, P(q.cuda()), P(k.cuda()), P(v.cuda()), P(o2), B, H, S, hd, scale,
+                                            P(p.float().cuda().contiguous()), 2 * npad, size, size))
+    close(o, o2.double().cpu(), 2e-5, "tables vs P buffer")
+    assert lib.anyref_op_attention_tab(SP, None, P(q.cuda()), P(k.cuda()), P(v.cuda()), P(o), B, H, S - 4, hd, scale,
+                                       P(tab[0]), P(tab[1]), ld, size, size) != 0      # Sq != kh * kw
+
+
 def test_split_pair_attention_ragged_kv_len(lib):
     from test_gpu_ops import ref_attention
     B, H, Sq, Sk, hd = 3, 4, 100, 300, 128
