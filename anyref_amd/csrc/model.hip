@@ -157,6 +157,9 @@ class Model : public ModelBase {
   Model(const anyref_config& c, int device) : ModelBase(c, device) {
     fp8w_ = c.mode == ANYREF_MODE_PERF_FP8W;
     if (fp8w_ && sizeof(T) != 2) throw std::runtime_error("fp8 weights need the bf16 compute mode");
+    // the split-pair encoder is twice as long as the 16-bit one: spread over 8 decode steps instead of 6
+    // (scratch/side_share.py, parity16 at C2: 49.2 - 49.9 ms with 6, 48.3 - 48.6 with 8 - 10; caps other than 128 lose 1 - 10 ms)
+    if (SPS && !getenv("ANYREF_SIDE_STEPS")) side_steps_ = 8;
   }
   ~Model() override {
     (void)hipSetDevice(device_);
@@ -1447,6 +1450,15 @@ void Model<T, TS>::sam_encoder(hipStream_t s, const float* images, int B, float*
   const int nblk = (int)sam_blocks_.size();
   const bool to_end = blk1 < 0 || blk1 >= nblk;
   if (to_end) blk1 = nblk;
+  // Several images, whole tower in one call: one image at a time through all blocks.  A batch of 4 at SAM-H moves 84 MB of f32
+  // residual stream + 126 MB of q / k / v + 168 MB of MLP activations per block -- past the L2s and most of the Infinity Cache --
+  // while one image's 21 / 31 / 42 MB stay on chip between the launches that write and read them (scratch/sam_batch_split.py)
+  static const bool per_image = !(getenv("ANYREF_SAM_PER_IMAGE") && atoi(getenv("ANYREF_SAM_PER_IMAGE")) == 0);
+  if (B > 1 && per_image && blk0 == 0 && to_end) {
+    for (int b = 0; b < B; ++b)
+      sam_encoder(s, images + (size_t)b * 3 * c.sam_img * c.sam_img, 1, out + (size_t)b * NT * C, 0, -1);
+    return;
+  }
   if (blk0 == 0) {
     launch_im2col_patch<TS>(images, B, c.sam_img, c.sam_patch, s_col_, sam_patch_.k, s);
     GemmArgs a;

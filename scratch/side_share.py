@@ -10,7 +10,7 @@ caps = [tuple(int(v) for v in x.split(":")) for x in sys.argv[1:]] or [(0, 6), (
 cfg = config_7b(); cfg.llm.max_seq = 512
 sd = synth_state_dict(cfg, seed=0, device="cuda", dtype=torch.bfloat16)
 clip, sam, ids = make_inputs(cfg, 1, seed=1); clip, sam = clip.cuda(), sam.cuda()
-m = AnyRefForCausalLM.from_state_dict(cfg, sd, mode="perf", max_batch=1, max_seg=2); m.config.eos_token_id = None
+m = AnyRefForCausalLM.from_state_dict(cfg, sd, mode=os.environ.get("ANYREF_LAB_MODE", "perf"), max_batch=1, max_seg=2); m.config.eos_token_id = None
 sizes, H, W = [(1024, 1024)], [1024], [1024]
 o, _, _ = m.generate(clip, ids, sam, sizes, H, W, max_new_tokens=10)
 m.set_seg_token_idx(int(o[0, ids.shape[1] + 2]))
