@@ -1450,10 +1450,11 @@ void Model<T, TS>::sam_encoder(hipStream_t s, const float* images, int B, float*
   const int nblk = (int)sam_blocks_.size();
   const bool to_end = blk1 < 0 || blk1 >= nblk;
   if (to_end) blk1 = nblk;
-  // Several images, whole tower in one call: one image at a time through all blocks.  A batch of 4 at SAM-H moves 84 MB of f32
-  // residual stream + 126 MB of q / k / v + 168 MB of MLP activations per block -- past the L2s and most of the Infinity Cache --
-  // while one image's 21 / 31 / 42 MB stay on chip between the launches that write and read them (scratch/sam_batch_split.py)
-  static const bool per_image = !(getenv("ANYREF_SAM_PER_IMAGE") && atoi(getenv("ANYREF_SAM_PER_IMAGE")) == 0);
+  // Lab knob (ANYREF_SAM_PER_IMAGE=1, default off): several images as one image at a time through all blocks.  The premise -- a
+  // batch's activations (4 images: 84 MB residual + 126 MB q / k / v + 168 MB MLP per block) fall out of the caches -- does not
+  // hold: scratch/sam_batch_split.py, SAM-H alone, B = 4: 31.2 ms in one call (7.8 per image) vs 34.3 ms as four (8.6); only
+  // B = 2 loses in one call (18.3 vs 17.2 ms: tile rounds at M = 8192); parity16 59.7 vs 65.5 ms.
+  static const bool per_image = getenv("ANYREF_SAM_PER_IMAGE") && atoi(getenv("ANYREF_SAM_PER_IMAGE")) != 0;
   if (B > 1 && per_image && blk0 == 0 && to_end) {
     for (int b = 0; b < B; ++b)
       sam_encoder(s, images + (size_t)b * 3 * c.sam_img * c.sam_img, 1, out + (size_t)b * NT * C, 0, -1);
