@@ -336,6 +336,339 @@ __global__ __launch_bounds__(512) void gemv_kernel(GemvArgs a, int b0, int nb) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Decode GEMV for 5 - 8 batch rows (bf16 activations; bf16 or fp8 weights), ONE pass over the weights.
+//
+// The packed-dot kernel above multiplies a weight row by every batch row on the VALU and re-reads the batch rows' x chunks from
+// LDS for every 16 bytes of weights: at 8 rows that is VALU- and LDS-bound (8-row packed dot, fp8: 1.0 - 1.5 TB/s; two 4-row
+// passes: every byte twice), and the tiled GEMM (M = 8 rows of a 64-row tile) streamed the decode rows' weights at 2 TB/s.
+// Here the products go to the matrix cores WITHOUT giving up the GEMV's row-contiguous loads: v_mfma_f32_4x4x4 (sixteen
+// independent 4 x 4 x 4 blocks per wave instruction) takes lane 4 q + j as (row j, K positions of block q), so a 16-byte load
+// per lane is FOUR weight rows x 256 contiguous bytes (16 lanes per row) -- the MFMA-native 16 x 16 x 32 layout is 16 rows x 64
+// bytes per load instruction and streams at ~4 TB/s (round 3 / 4 negative results).  Block q multiplies its K positions of the
+// four rows by the same K positions of four batch rows (B operand: 8 bytes per lane from the LDS x stage, two MFMAs cover
+// eight batch rows) and keeps a 4 x 4 partial sum; the sixteen blocks are added by an xor butterfly at the end of a row group.
+// fp8 weights are widened to packed bf16 pairs by v_cvt_scalef32_pk_bf16_fp8 (scale 1, exact): 8 VALU + 8 MFMA instructions per
+// 16-byte load instead of 144 VALU.  x stage: row stride = 64 bytes modulo 256 and (fp8) the two 16-byte halves of a block's 16
+// positions in two planes, so the 16 lanes of a read phase (4 batch rows x 4 blocks) tile the banks.
+// K longer than the LDS stage (down_proj: 11008 / 13824) is taken as TWO K halves inside the launch (x restaged behind a
+// barrier, the sums of the wave's one row group stay in registers); inputs with an RMSNorm (K <= 6144) in one.
+// Weights are LOADED row-contiguous (lane 16 j + q: 256 bytes of a row per 16 lanes) and turned into the MFMA's lane order by
+// four ds_bpermute per 16-byte load; three chunk buffers (this item + two in flight, 8 KB per wave each) rotate through moves.
+// Measured (scratch/bench_gemv8.py under rocprofv3, cold weights, 8 rows, us per launch; 13B shapes):
+//   fp8  qkv 27.9 (2.8 TB/s)  o 14.3 - 23  gate/up 41.5 (3.4 TB/s)  down 30 (two K halves);  two 4-row passes: 80 / 43 / 122 / 74
+//   bf16 qkv 34.8 (4.5 TB/s)  gate/up 57.8 (4.9 TB/s);  two 4-row passes: 79 / 112
+// The main loop streams at the HBM rate (time = bytes / 6 TB/s + ~12 us): 2.5 us launch + 5 us x stage of 8 rows + ~3 us first
+// chunk + tail.  C5 (13B fp8, batch 8): 186.0 -> 181.1 ms per batch against the split-K GEMM decode path (M = 8 rows of a
+// 64 / 128-row tile at 1.9 TB/s); 7B bf16 at batch 8: decode step 4.13 -> 4.15 ms alone, 132.4 -> 128.5 ms per call with masks.
+// ---------------------------------------------------------------------------------------------
+template <bool W8, bool DUAL, int XV>  // XV: float4 of x per thread and row in the RMSNorm staging (K <= 2048 XV)
+__global__ __launch_bounds__(512) void gemv_rows8_kernel(GemvArgs a, int b0, int nb, int kh0, int rs) {
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+  constexpr int NB = 8, UNR = 8;
+  constexpr int EPL = W8 ? 16 : 8;       // weights per lane and load
+  constexpr int SEG = 16 * EPL;          // K positions one load instruction covers per row (16 lanes)
+  constexpr int CH = UNR * SEG;          // ... one chunk
+  using WT = std::conditional_t<W8, uint8_t, bf16>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ float red[NB][8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 3, q = lane >> 2;
+  const int K = a.K;
+  const int ldw = a.ldw > 0 ? a.ldw : K;
+  const WT* __restrict__ W = reinterpret_cast<const WT*>(a.W);
+  const WT* __restrict__ W2 = reinterpret_cast<const WT*>(a.W2);
+  constexpr int R = DUAL ? 2 : 4;  // outputs per row group
+  const int ngroups = cdiv(a.N, R);
+  const int nwaves = gridDim.x * 8, gw = blockIdx.x * 8 + wave;
+  const int my_groups = gw < ngroups ? (ngroups - gw + nwaves - 1) / nwaves : 0;
+  const int nkh = kh0 < K ? 2 : 1;
+  const int nch0 = cdiv(kh0, CH), nch1 = nkh == 2 ? cdiv(K - kh0, CH) : 0;
+  // items in (K half, group, chunk) order, one chunk prefetched
+  const int items0 = my_groups * nch0, items = items0 + my_groups * nch1;
+  const int pl = rs > 0 ? (rs - 64) / 2 : 0;  // plane size in bytes (fp8: two planes per row)
+  uint4v w0[UNR], w1[UNR], w2[UNR];  // this item's weights and the next two items' in flight (8 KB per wave each)
+  auto item_pos = [&](int t, int& g, int& kbeg, int& kend) __attribute__((always_inline)) {
+    int gi, c;
+    if (t < items0) {
+      gi = t / nch0; c = t - gi * nch0;
+      kbeg = c * CH; kend = kh0;
+    } else {
+      const int t1 = t - items0;
+      gi = t1 / nch1; c = t1 - gi * nch1;
+      kbeg = kh0 + c * CH; kend = K;
+    }
+    g = gw + gi * nwaves;
+  };
+  auto load_item = [&](int t, uint4v (&w)[UNR]) __attribute__((always_inline)) {
+    int g, kbeg, kend;
+    item_pos(t, g, kbeg, kend);
+    // LOADED row-contiguous: lane 16 jl + ql takes 16 bytes of row jl at block ql (16 lanes = 256 contiguous bytes: four 64-byte
+    // requests; with the MFMA's own lane order, 4 q + j, every 16-byte piece of a wave load is a request of its own and the
+    // launch streams at 1.3 - 1.8 TB/s) and turned into the MFMA order by ds_bpermute when it is used (mma_item)
+    // rows 4 g .. 4 g + 3, or (SwiGLU) gate rows 2 g, 2 g + 1 and up rows 2 g, 2 g + 1
+    const int jl = lane >> 4, ql = lane & 15;
+    int n = DUAL ? g * 2 + (jl & 1) : g * 4 + jl;
+    n = n < a.N ? n : a.N - 1;
+    const WT* row = ((DUAL && jl >= 2) ? W2 : W) + (int64_t)n * ldw;
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int k = kbeg + u * SEG + ql * EPL;
+      w[u] = k < kend ? __builtin_nontemporal_load(reinterpret_cast<const uint4v*>(row + k)) : uint4v{0, 0, 0, 0};
+    }
+  };
+  // LDS position (bytes) of K position kl (multiple of 4) of batch row b inside the current stage
+  auto xpos = [&](int b, int kl) __attribute__((always_inline)) {
+    if constexpr (W8) return b * rs + ((kl >> 3) & 1) * pl + (kl >> 4) * 16 + (kl & 7) * 2;
+    else return b * rs + kl * 2;
+  };
+  if (items > 0) load_item(0, w0);
+  if (items > 1) load_item(1, w1);
+  float scale[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) scale[b] = 1.f;
+  if (a.gain) {
+    // RMSNorm inputs (one K stage): rows through registers, sums of squares of all rows behind one barrier
+    float4v xr[NB][XV], gr[XV];
+#pragma unroll
+    for (int i = 0; i < XV; ++i) {
+      const int k = (tid + i * 512) * 4;
+      gr[i] = k < K ? *reinterpret_cast<const float4v*>(a.gain + k) : float4v{1.f, 1.f, 1.f, 1.f};
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const float* x = a.x + (int64_t)(b0 + (b < nb ? b : 0)) * a.ldx;
+#pragma unroll
+      for (int i = 0; i < XV; ++i) {
+        const int k = (tid + i * 512) * 4;
+        xr[b][i] = (b < nb && k < K) ? *reinterpret_cast<const float4v*>(x + k) : float4v{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      float ss = 0.f;
+#pragma unroll
+      for (int i = 0; i < XV; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ss += xr[b][i][e] * xr[b][i][e];
+      ss = wave_sum(ss);
+      if (lane == 0) red[b][wave] = ss;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      float tot = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) tot += red[b][w];
+      scale[b] = rsqrtf(tot / (float)K + a.eps);
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+#pragma unroll
+      for (int i = 0; i < XV; ++i) {
+        const int k = (tid + i * 512) * 4;
+        if (k < K) {
+          const float4v v = xr[b][i] * scale[b] * gr[i];  // rows >= nb: zeros
+          store4_from_f32<bf16>(reinterpret_cast<bf16*>(smem + xpos(b, k)), v[0], v[1], v[2], v[3]);
+          if (a.xn_out && blockIdx.x == 0 && b < nb)
+            *reinterpret_cast<float4v*>(a.xn_out + (int64_t)(a.xn_row_map ? a.xn_row_map[b0 + b] : b0 + b) * a.xn_ld + k) = v;
+        }
+      }
+    }
+  }
+  auto stage_plain = [&](int kbase, int klen) __attribute__((always_inline)) {  // f32 -> bf16 copy of x[:, kbase : kbase + klen) (no norm)
+    // four rows at a time, every load of the four in flight before the first LDS store (a load -> store loop over rows and
+    // 2048-column pieces is ~24 dependent L2 round trips: 6 us of a 17 us o_proj launch)
+    constexpr int NI = 5;  // float4 per thread and row: stage <= 9472 columns
+    const int n4 = klen / 4;
+#pragma unroll
+    for (int bb = 0; bb < NB; bb += 4) {
+      float4v r[4][NI];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const float* x = a.x + (int64_t)(b0 + (bb + b < nb ? bb + b : 0)) * a.ldx + kbase;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          const int c = tid + i * 512;
+          r[b][i] = (bb + b < nb && c < n4) ? *reinterpret_cast<const float4v*>(x + c * 4) : float4v{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          const int c = tid + i * 512;
+          if (c < n4) store4_from_f32<bf16>(reinterpret_cast<bf16*>(smem + xpos(bb + b, c * 4)), r[b][i][0], r[b][i][1], r[b][i][2], r[b][i][3]);
+        }
+    }
+  };
+  if (!a.gain) stage_plain(0, kh0);
+  __syncthreads();
+
+  float4v ac[2];  // [batch rows 0-3 | 4-7] of the current row group (two-K-half launches: the wave's only group)
+  ac[0] = ac[1] = float4v{0.f, 0.f, 0.f, 0.f};
+  auto mma_item = [&](const uint4v (&wcur)[UNR], int kbeg_l, int kend_l) __attribute__((always_inline)) {  // kbeg_l: chunk start inside the current stage
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      // (no branch: a masked load is sixteen zero bytes and every lane must take part in the permute; positions past the end of
+      //  the stage read the x of position 0 -- finite values against zero weights)
+      int kl = kbeg_l + u * SEG + q * EPL;
+      kl = kl < kend_l ? kl : 0;
+      {
+        // x of this block's positions for batch rows j and j + 4
+        uint4v xa[2][W8 ? 2 : 1];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          xa[h][0] = *reinterpret_cast<const uint4v*>(smem + xpos(j + 4 * h, kl));
+          if constexpr (W8) xa[h][1] = *reinterpret_cast<const uint4v*>(smem + xpos(j + 4 * h, kl + 8));
+        }
+        // weights of (row j, block q) from the lane that loaded them
+        uint32_t wt[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wt[e] = (uint32_t)__builtin_amdgcn_ds_bpermute((16 * j + q) * 4, (int)wcur[u][e]);
+#pragma unroll
+        for (int m = 0; m < EPL / 4; ++m) {
+          short4v_ af;
+          if constexpr (W8) {
+            const uint32_t wj = wt[m];
+            const bf16x2 lo = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(wj, 1.0f, false);
+            const bf16x2 hi = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(wj, 1.0f, true);
+            const uint2v t = uint2v{__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi)};
+            af = __builtin_bit_cast(short4v_, t);
+          } else {
+            const uint32_t w0 = wt[2 * m], w1 = wt[2 * m + 1];
+            const uint2v t = uint2v{w0, w1};
+            af = __builtin_bit_cast(short4v_, t);
+          }
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const uint32_t x0 = xa[h][m >> 1][2 * (m & 1)], x1 = xa[h][m >> 1][2 * (m & 1) + 1];
+            const uint2v t = uint2v{x0, x1};
+            ac[h] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(af, __builtin_bit_cast(short4v_, t), ac[h], 0, 0, 0);
+          }
+        }
+      }
+    }
+  };
+  auto finish_group = [&](int g) __attribute__((always_inline)) {
+    // add the sixteen blocks' partial sums (lanes of equal j), then lane l < 8 finishes batch row (l & 3) + 4 (l >> 2)
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = ac[h][r];
+        v += __shfl_xor(v, 4, 64);
+        v += __shfl_xor(v, 8, 64);
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        ac[h][r] = v;
+      }
+    if (lane < 8) {
+      const int b = (lane & 3) + 4 * (lane >> 2);
+      const float4v t = (lane >> 2) ? ac[1] : ac[0];
+      float v[4] = {t[0], t[1], t[2], t[3]};  // D[i = weight row][this lane's batch row]
+      if (b < nb) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int n = g * R + r;
+          if (n >= a.N) continue;
+          float o = v[r], o2 = DUAL ? v[r + 2] : 0.f;
+          if constexpr (W8) {
+            o *= a.wscale[(int64_t)n * a.ws_stride];
+            if (DUAL) o2 *= a.wscale2[(int64_t)n * a.ws_stride];
+          }
+          if (a.bias) o += a.bias[n];
+          if (DUAL) o = apply_act(o, ACT_SILU) * o2;
+          else o = apply_act(o, a.act);
+          const int64_t off = (int64_t)(b0 + b) * a.ldy + n;
+          if (a.resid) o += a.resid[off];
+          a.y[off] = o;
+        }
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) ac[h] = float4v{0.f, 0.f, 0.f, 0.f};
+  };
+  // (one copy of the multiply code: the three buffers rotate through register moves, 64 v_mov per 64 MFMAs)
+  auto run = [&](int t_begin, int t_end) __attribute__((always_inline)) {
+    for (int t = t_begin; t < t_end; ++t) {
+      if (t + 2 < items) load_item(t + 2, w2);  // (chunks of the second K half are requested before its x is staged)
+      int g, kbeg, kend;
+      item_pos(t, g, kbeg, kend);
+      const bool second = t >= items0;
+      const int base = second ? kh0 : 0;
+      mma_item(w0, kbeg - base, kend - base);
+      const int nch = second ? nch1 : nch0, tt = second ? t - items0 : t;
+      const bool last_chunk = tt % nch == nch - 1;
+      if (last_chunk && (nkh == 1 || second)) finish_group(g);
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        w0[u] = w1[u];
+        w1[u] = w2[u];
+      }
+    }
+  };
+  run(0, items0);
+  if (nkh == 2) {  // every wave of the workgroup, with or without a row group of its own
+    __syncthreads();
+    stage_plain(kh0, K - kh0);
+    __syncthreads();
+    run(items0, items);
+  }
+}
+
+// 5 - 8 rows of a bf16 GEMV in one pass (gemv_rows8_kernel); false: shape not taken (the caller falls back to passes of 4)
+static bool gemv_rows8_launch(const GemvArgs& a, int b0, int nb, hipStream_t s) {
+  static const bool off = getenv("ANYREF_GEMV_ROWS8") && atoi(getenv("ANYREF_GEMV_ROWS8")) == 0;
+  if (off) return false;
+  const bool w8 = a.w_fp8 != 0, dual = a.W2 != nullptr;
+  const int epl = w8 ? 16 : 8, ch = 8 * 16 * epl;
+  const int ldw = a.ldw > 0 ? a.ldw : a.K;
+  const size_t wsz = w8 ? 1 : 2;
+  if (a.K % epl || (ldw * wsz) % 16 || ((uintptr_t)a.W & 15) || (dual && ((uintptr_t)a.W2 & 15)) || a.K % 4) return false;
+  constexpr int KH_MAX = 9472;  // 8 rows x (2 KH_MAX rounded to 256 + 64) bytes <= 150 KB
+  int kh0 = a.K;
+  if (a.gain) {
+    if (a.K > 6144) return false;  // (rows through registers: 24 float4 per thread)
+  } else if (a.K > KH_MAX) {
+    kh0 = cdiv(cdiv(a.K, 2), ch) * ch;
+    if (kh0 > KH_MAX || kh0 >= a.K) return false;
+    if (cdiv(a.N, dual ? 2 : 4) > 256 * 8) return false;  // a wave keeps the sums of its ONE row group across the halves
+  }
+  const int rs = cdiv(kh0 * 2, 256) * 256 + 64;
+  const size_t lds = (size_t)8 * rs;
+  const int grid = 256;
+  const double wbytes = (double)a.N * a.K * wsz * (dual ? 2 : 1) + (double)nb * (a.K + a.N) * 4;
+  char tag[48];
+  snprintf(tag, sizeof(tag), "gemv_rows8_%s%s", w8 ? "fp8w" : "bf16", dual ? "_swiglu" : "");
+  ProfScope prof(tag, 2.0 * nb * a.N * (double)a.K * (dual ? 2 : 1), wbytes, s);
+  auto launch = [&](auto w8_t, auto dual_t, auto xv_t) {
+    constexpr bool W8 = decltype(w8_t)::value, DUAL = decltype(dual_t)::value;
+    constexpr int XV = decltype(xv_t)::value;
+    auto kern = &gemv_rows8_kernel<W8, DUAL, XV>;
+    static KernelAttrOnce once;
+    ensure_dyn_lds(once, reinterpret_cast<const void*>(kern), 152 * 1024);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, a, b0, nb, kh0, rs);
+  };
+  using TT = std::true_type;
+  using FF = std::false_type;
+  using X2 = std::integral_constant<int, 2>;
+  using X3 = std::integral_constant<int, 3>;
+  auto by_xv = [&](auto w8_t, auto dual_t) {
+    if (a.gain && a.K > 4096) launch(w8_t, dual_t, X3());
+    else launch(w8_t, dual_t, X2());
+  };
+  if (w8) {
+    if (dual) by_xv(TT(), TT());
+    else by_xv(TT(), FF());
+  } else {
+    if (dual) by_xv(FF(), TT());
+    else by_xv(FF(), FF());
+  }
+  return true;
+}
+
 template <typename T, int NB>
 static void gemv_dispatch(const GemvArgs& a_in, int b0, int nb, hipStream_t s) {
   GemvArgs a = a_in;
@@ -405,14 +738,23 @@ void launch_gemv(const GemvArgs& a, hipStream_t s) {
       (a.xn_out && (((uintptr_t)a.xn_out & 15) || a.xn_ld % 4)))
     throw std::runtime_error("gemv: x / gain / xn_out rows must be 16-byte aligned");
   constexpr int NBMAX = sizeof(T) == 2 ? 4 : 2;
-  for (int b0 = 0; b0 < a.B; b0 += NBMAX) {
-    const int nb = a.B - b0 < NBMAX ? a.B - b0 : NBMAX;
+  for (int b0 = 0; b0 < a.B;) {
+    const int left = a.B - b0;
+    if constexpr (std::is_same<T, bf16>::value) {
+      // 5 - 8 rows left: one pass over the weights on the 4 x 4 x 4 MFMA form where the shape allows
+      if (left > 4 && gemv_rows8_launch(a, b0, left < 8 ? left : 8, s)) {
+        b0 += left < 8 ? left : 8;
+        continue;
+      }
+    }
+    const int nb = left < NBMAX ? left : NBMAX;
     if (nb == 1)
       gemv_dispatch<T, 1>(a, b0, nb, s);
     else if (nb == 2)
       gemv_dispatch<T, 2>(a, b0, nb, s);
     else
       gemv_dispatch<T, NBMAX>(a, b0, nb, s);
+    b0 += nb;
   }
 }
 template void launch_gemv<float>(const GemvArgs&, hipStream_t);

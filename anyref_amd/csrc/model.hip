@@ -1347,7 +1347,10 @@ void Model<T, TS>::llm_decode_step(hipStream_t s, int B, bool keep_q) {
   // More than 4 sequences per call: the FMA GEMV would stream every weight twice (4 batch rows per pass) and
   // its VALU work grows with B, so the linears go through the MFMA GEMM (M = B rows of a 64/128-row tile,
   // split-K to fill the chip: weights are read once) with the norms / SwiGLU as in prefill.
-  const bool mfma_decode = IS16 && B > 4;
+  // (bf16 activations: up to 8 sequences stay on the GEMV -- 8 rows per pass over the q / k / v, o and gate / up weights, two passes
+  //  of four over down_proj; the tiled GEMM streamed the decode rows' weights at 2 TB/s.  ANYREF_GEMV_ROWS8=0: the round-4 rule)
+  static const bool rows8 = !(getenv("ANYREF_GEMV_ROWS8") && atoi(getenv("ANYREF_GEMV_ROWS8")) == 0);
+  const bool mfma_decode = IS16 && B > ((std::is_same<T, bf16>::value && rows8) ? 8 : 4);
   bool h_ready = false;
   for (int i = 0; i < nl; ++i) {
     LlmLayer& L = llm_layers_[i];

@@ -355,14 +355,15 @@ def test_decode_mfma_path_batch_gt4(mode):
             assert herr < PERF_HIDDEN_REL * hscale, f"row {b}: hidden err vs oracle {herr}"
 
 
-@pytest.mark.parametrize("mode,B", [("parity", 1), ("perf", 1), ("perf", 4), ("perf", 8), ("parity", 4)])
+@pytest.mark.parametrize("mode,B", [("parity", 1), ("perf", 1), ("perf", 4), ("perf", 8), ("perf", 12), ("parity", 4)])
 def test_generate_llama7b_shaped_layers_vs_oracle(mode, B):
     """Two decoder layers at LLaMA-7B's real widths (4096 / 32 heads of 128 / MLP 11008; vocab 1000) behind the tiny
     vision towers: prefill and the decode steps run the shapes the headline run uses -- 64x256 and split-K GEMM
     tiles with the fused norm / SwiGLU epilogues, and the decode GEMVs over the padded weight rows (K = 4096 and the
     16-byte-staged K = 11008) -- and every hidden state (prompt rows from prefill, new rows from decode) is held
     against the CPU fp32 oracle.  B = 4 is BASELINE configs[2]'s per-GPU batch (4 rows per pass of the decode
-    GEMV), B = 8 takes the MFMA decode path (weights read once per step)."""
+    GEMV), B = 8 the one-pass 8-row GEMV (gemv_rows8_kernel: 4 x 4 x 4 MFMA blocks, down_proj as two K halves), B = 12
+    the MFMA decode path (M = B rows of a GEMM tile, split-K; weights read once per step)."""
     import dataclasses
     from anyref_amd.config import LlmConfig
     from anyref_amd.model import AnyRefForCausalLM

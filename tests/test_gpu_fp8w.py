@@ -44,8 +44,8 @@ def test_quantiser_bit_exact(N, K):
 
 @pytest.mark.parametrize("B,N,K,dual,norm", [(1, 512, 256, False, True), (2, 96, 688, False, False),
                                               (1, 688, 256, True, True), (4, 40, 4096, False, True),
-                                              # 5 .. 8 rows: the matrix-core GEMV (gemv_mfma_kernel, fp8 weights widened per
-                                              # fragment); K = 13824: down_proj at 13B, taken as K chunks (x stage of 8 rows)
+                                              # 5 .. 8 rows: one pass on the 4 x 4 x 4 MFMA form (gemv_rows8_kernel, fp8 pairs widened
+                                              # to packed bf16); K = 13824 / 11008: down_proj, two K halves inside the launch
                                               (8, 1000, 5120, False, True), (8, 688, 5120, True, True), (5, 100, 256, False, False),
                                               (8, 5120, 13824, False, False), (6, 130, 11008, False, False)])
 def test_gemv_fp8_vs_torch(B, N, K, dual, norm):
@@ -238,10 +238,11 @@ def test_generate_fp8w_matches_oracle_on_dequantised_weights():
 def test_c5_full_depth_batch8_mfma_decode_vs_batch1_gemv():
     """BASELINE configs[4] at FULL depth (13B: 40 layers x 5120 / 13824, fp8 weights, SAM-H, 1024^2, batch 8).  A 13B fp32
     oracle does not fit the host budget of `-m gpu`, so this is a GPU-side consistency test of the two decode paths the
-    shape selects: the eight rows through ONE batched call (prefill GEMMs at M = 8 x 320 rows, 8 SAM-H encodes, the MFMA
-    decode path: fp8 weights through the split-K GEMM, read once per step) against the same rows one at a time (B = 1: the
-    fp8 decode GEMVs).  Both round activations to bf16 at the same points and multiply the same fp8 bytes, so they differ
-    by summation order only: hidden states within the bf16 bound, greedy ids identical on the peaked (fan-in) workload.
+    shape selects: the eight rows through ONE batched call (prefill GEMMs at M = 8 x 320 rows, 8 SAM-H encodes, the 8-row
+    decode GEMV: fp8 pairs widened to packed bf16 for the 4 x 4 x 4 MFMA, every weight read once per step, down_proj as two
+    K halves) against the same rows one at a time (B = 1: the fp8 packed-FMA decode GEMVs).  Both round activations to bf16 at
+    the same points and multiply the same fp8 bytes, so they differ by summation order only: hidden states within the bf16
+    bound, greedy ids identical on the peaked (fan-in) workload.
     (Reduced-depth parity of each path against the CPU oracle: test_generate_13b_shaped_layers_fp8w_batch8_vs_oracle.)"""
     import gc
     from anyref_amd.config import config_13b, IMAGE_TOKEN_INDEX

@@ -138,7 +138,7 @@ def test_gemm_a_row_gather(lib, ty, M, Msrc, N, K, c_f32):
                                              # K = 13824 -> 32, neither a multiple of 512 * 8) and the ragged lm_head
                                              (1, 640, 5120, 0, 1), (2, 130, 5120, 1, 1), (1, 64, 13824, 0, 0),
                                              (4, 40, 13824, 0, 1), (2, 96, 13824, 1, 0), (1, 32007, 4096, 0, 1),
-                                             # 5 .. 8 rows (bf16: the matrix-core GEMV; K = 11008 / 13824 as K chunks)
+                                             # 5 .. 8 rows (bf16: ONE pass on the 4 x 4 x 4 MFMA form, gemv_rows8_kernel; K = 11008 / 13824 as two K halves)
                                              (8, 12288, 4096, 0, 1), (8, 1000, 4096, 1, 1), (5, 100, 256, 0, 0), (7, 4096, 11008, 0, 0),
                                              (8, 5120, 13824, 0, 0), (6, 33, 5120, 1, 1)])
 def test_gemv(lib, ty, B, N, K, dual, norm):
