@@ -359,6 +359,23 @@ def main():
             roofline = dict(max(parts, key=lambda r: r["ms_per_step"]))
             if len(parts) > 1:
                 roofline["parts"] = parts
+            # the same launches with the co-running SAM stream off (event brackets of two busy streams include the time a
+            # launch waits for CUs the other stream holds): what rocprofv3 --kernel-trace of an overlap-off run can check
+            model.set_overlap(False)
+            model.profile_enable(True)
+            step()
+            iso_table = model.profile_read()
+            model.profile_enable(False)
+            model.set_overlap(True)
+            iso_sel = {k: v for k, v in iso_table.items() if family(k) == dom and v["count"]}
+            iso_dec = {k: v for k, v in iso_sel.items() if k.endswith("_dec")} if compute else {}
+            iso_rest = {k: v for k, v in iso_sel.items() if k not in iso_dec}
+            iso_parts = ([part(iso_rest, compute, "prefill / encoder launches (M > 16 rows)" if iso_dec else "all")] if iso_rest else []) + \
+                        ([part(iso_dec, False, "decode launches (M <= 16 rows: weight streaming)")] if iso_dec else [])
+            if iso_parts:
+                iso_main = max(iso_parts, key=lambda r: r["ms_per_step"])
+                roofline["isolated"] = {k: iso_main[k] for k in ("launches", "bound", "achieved", "peak", "unit", "frac", "ms_per_step")}
+                roofline["isolated"]["note"] = "same eager step, SAM-encoder overlap off (no co-running stream)"
         breakdown = {k: dict(ms_per_step=round(v["ms"], 3), launches=v["count"],
                              tflops=round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 1),
                              gbs=round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1)) for k, v in sorted(
