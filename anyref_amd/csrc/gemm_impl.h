@@ -1135,6 +1135,15 @@ void launch_gemm(const GemmArgs& a_in, hipStream_t s) {
           return;
         }
       }
+      if constexpr (!is_half16<T>::value) {
+        // CLIP qkv / fc1 (257 x 3072 / 4096 x 1024): 72 / 96 workgroups of 128^2 stream 32 KB per K tile each through L2 -> LDS
+        // (~0.5 us x 16 K tiles + ~4 us of launch, first tile and epilogue); 64 x 128 tiles are 120 / 160 workgroups at 24 KB
+        static const bool clip64 = !(getenv("ANYREF_GEMM_CLIP64") && atoi(getenv("ANYREF_GEMM_CLIP64")) == 0);
+        if (clip64 && !a.w_fp8 && a.batch == 1 && a.M > 128 && a.M <= 320 && a.N >= 2048 && a.N < 8192 && a.K <= 2048 && t128 <= cus) {
+          go(I64(), I128(), I1(), I4(), I3(), "gemm_bf16_64x128s3");
+          return;
+        }
+      }
       if (t128 <= cus)
         go(I128(), I128(), I2(), I4(), I3(), "gemm_bf16_128x128s3");
       else
