@@ -1129,6 +1129,18 @@ void launch_gemm(const GemmArgs& a_in, hipStream_t s) {
           go(I320(), I64(), I4(), I2(), I3(), "gemm_bf16_320x64");
           return;
         }
+        {
+          // prefill o_proj / down_proj at FOUR sequences (1280 x 4096 x 4096 / 11008: C3's per-GPU shape): 320 tiles of 128^2 are 1.25
+          // workgroups per CU -- 64 CUs carry two and set the launch's time (2 x 64 K tiles x 32 KB through one CU's L2 -> LDS
+          // path: 63 / 158 us) -- while 4 x 64 tiles of 320 x 64 are exactly one per CU (64 K tiles x 49 KB)
+          static const bool m320x4 = !(getenv("ANYREF_GEMM_M320X4") && atoi(getenv("ANYREF_GEMM_M320X4")) == 0);
+          const int64_t t320x64 = (int64_t)cdiv(a.M, 320) * cdiv(a.N, 64);
+          if (m320x4 && !a.w_fp8 && a.batch == 1 && a.M > 512 && a.M <= 2560 && a.K >= 2048 && t320x64 <= cus && t320x64 * 10 >= cus * 9 &&
+              fill128 < 0.7) {
+            go(I320(), I64(), I4(), I2(), I3(), "gemm_bf16_320x64");
+            return;
+          }
+        }
         if (a.M <= 512 && a.N >= 8192) {
           if (t64w <= cus) go(I64(), I256(), I1(), I4(), I3(), "gemm_bf16_64x256s3");
           else go(I64(), I256(), I1(), I4(), I2(), "gemm_bf16_64x256");
