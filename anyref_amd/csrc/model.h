@@ -99,6 +99,10 @@ class ModelBase {
   int side_wgs_ = getenv("ANYREF_SIDE_WGS") ? atoi(getenv("ANYREF_SIDE_WGS")) : 128;
   int side_steps_ = getenv("ANYREF_SIDE_STEPS") ? atoi(getenv("ANYREF_SIDE_STEPS")) : 6;
   int side_head_ = getenv("ANYREF_SIDE_HEAD") ? atoi(getenv("ANYREF_SIDE_HEAD")) : 3;  // encoder blocks queued beside CLIP
+  // 2 - 4 images per call (C3's per-GPU shape): the same feeding at a larger share over fewer steps (model.hip generate)
+  int side_wgs_b_ = getenv("ANYREF_SIDE_WGS_B") ? atoi(getenv("ANYREF_SIDE_WGS_B")) : 160;
+  int side_steps_b_ = getenv("ANYREF_SIDE_STEPS_B") ? atoi(getenv("ANYREF_SIDE_STEPS_B")) : 3;
+  int side_cap_now_ = 0;  // the cap sam_feed applies during this call
 };
 
 std::unique_ptr<ModelBase> make_model(const anyref_config& cfg, int device);

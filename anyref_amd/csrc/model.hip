@@ -1117,7 +1117,7 @@ void Model<T, TS>::sam_feed(int upto, bool capped) {
   if (!sam_forked_ || sam_enq_done_) return;
   upto = std::min(upto, nblk);
   if (upto <= sam_next_blk_) return;
-  cap_wg_ = capped ? side_wgs_ : 0;
+  cap_wg_ = capped ? side_cap_now_ : 0;
   try {
     sam_encoder(s2_, sam_img_, sam_B_, sam_emb_, sam_next_blk_, upto);
   } catch (...) {
@@ -1916,8 +1916,15 @@ void Model<T, TS>::generate(hipStream_t s, const float* clip_images, const float
   // (the split-pair mode too: its GEMMs have the capped forms; its attention launches stay uncapped.  Same share / step
   //  count as perf, alternated on one box: 57.1 - 57.3 ms uncapped-after-prefill -> 52.7 - 53.3 ms fed; 160 / 192 / 96 workgroups
   //  or 9 steps: 53.2 - 55.8)
-  const bool fed = (B == 1 || any_b) && side_wgs_ > 0 && overlap_ && IS16;
-  const int per_step = std::max(1, (nblk + side_steps_ - 1) / std::max(1, side_steps_));
+  // Round 4: 2 - 4 images per call are fed too, at 160 workgroups over 3 steps (bench.py --config c3, one box, ms per 4-image
+  // call: whole / uncapped after prefill 81.5; fed at 128 x 9 steps 83.6, 128 x 3 85.1, 144 x 4 83.4, **160 x 3 77.7**, 160 x 6 78.1,
+  // 176 x 6 78.4, 192 x 2 - 9 78.3 - 78.9, 200 - 224: 80.6 - 80.9; without the head blocks beside CLIP 81.2; two images 56.3 -> 54.8).
+  // Eight images lose (128.7 -> 135.6 - 164.6 ms): whole, as before.
+  const int side_cap = B == 1 ? side_wgs_ : side_wgs_b_;
+  const bool fed = (B <= 4 || any_b) && side_cap > 0 && overlap_ && IS16;
+  const int steps_now = B == 1 ? side_steps_ : side_steps_b_;
+  side_cap_now_ = side_cap;
+  const int per_step = std::max(1, (nblk + steps_now - 1) / std::max(1, steps_now));
   if (fed) {
     fork_sam(s, sam_images, B, true);
     sam_feed(std::min(side_head_, nblk - 1), true);
