@@ -1927,7 +1927,13 @@ void Model<T, TS>::generate(hipStream_t s, const float* clip_images, const float
   const int per_step = std::max(1, (nblk + steps_now - 1) / std::max(1, steps_now));
   if (fed) {
     fork_sam(s, sam_images, B, true);
-    sam_feed(std::min(side_head_, nblk - 1), true);
+    {
+      // (lab knob: a share of its own for the blocks beside the CLIP tower, whose launches leave most CUs idle)
+      static const int head_wgs = getenv("ANYREF_SIDE_HEAD_WGS") ? atoi(getenv("ANYREF_SIDE_HEAD_WGS")) : 0;
+      if (head_wgs > 0) side_cap_now_ = head_wgs;
+      sam_feed(std::min(side_head_, nblk - 1), true);
+      side_cap_now_ = side_cap;
+    }
   }
   clip_tower(s, clip_images, B);
   std::vector<int> slen, img_pos;
