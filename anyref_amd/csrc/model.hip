@@ -1940,6 +1940,11 @@ void Model<T, TS>::generate(hipStream_t s, const float* clip_images, const float
   const int Sp = splice_inputs(s, input_ids, lens, B, Lmax, extra_embeds, extra_slots, n_extra, slen, img_pos);
   for (int b = 0; b < B; ++b)
     if (slen[b] + max_new_tokens > S) throw std::runtime_error("prompt + max_new_tokens exceeds llm_max_seq");
+  {
+    // (lab knob: encoder blocks queued beside prefill too; default none -- both are MFMA-bound)
+    static const int pf_blocks = getenv("ANYREF_SIDE_PREFILL_BLOCKS") ? atoi(getenv("ANYREF_SIDE_PREFILL_BLOCKS")) : 0;
+    if (fed && pf_blocks > 0) sam_feed(std::min(sam_next_blk_ + pf_blocks, nblk - 1), true);
+  }
   llm_prefill(s, B, Sp, slen_dev_, keep_q);
   // Fork the SAM encoder only now: CLIP + prefill are MFMA-bound themselves, the decode loop that
   // follows is HBM-bound and leaves the matrix cores to the encoder on the second stream.
