@@ -68,6 +68,7 @@ SYMBOLS = {
     "anyref_set_seg_range": (_I, [_P, _I, _I]),
     "anyref_set_overlap": (_I, [_P, _I]),
     "anyref_set_early_tail": (_I, [_P, _I]),
+    "anyref_set_extra_event": (_I, [_P, _P]),
     "anyref_set_graphs": (_I, [_P, _I]),
     "anyref_set_side_share": (_I, [_P, _I, _I]),
     "anyref_profile_enable": (_I, [_P, _I]),

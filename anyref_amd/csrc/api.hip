@@ -131,6 +131,7 @@ int anyref_set_seg_range(anyref_handle* h, int lo, int hi) { GUARD(h, h->m->set_
 
 int anyref_set_overlap(anyref_handle* h, int on) { GUARD(h, h->m->set_overlap(on != 0)); }
 int anyref_set_early_tail(anyref_handle* h, int on) { GUARD(h, h->m->set_early_tail(on != 0)); }
+int anyref_set_extra_event(anyref_handle* h, void* event) { GUARD(h, h->m->set_extra_event(event)); }
 
 int anyref_set_graphs(anyref_handle* h, int on) { GUARD(h, h->m->set_graphs(on != 0)); }
 int anyref_set_side_share(anyref_handle* h, int wgs, int steps) { GUARD(h, h->m->set_side_share(wgs, steps)); }

@@ -67,6 +67,10 @@ class ModelBase {
   void set_overlap(bool on) { overlap_ = on; }
   // masks of generated [SEG]s decoded on the side stream while the greedy loop goes on (default on; batch 1)
   void set_early_tail(bool on) { early_off_ = !on; }
+  // the NEXT generate / forward_teacher waits for this event on its stream just before it reads extra_embeds (the splice):
+  // the caller may produce them (ImageBind audio trunk + projector) on a stream of its own, beside the CLIP tower
+  void set_extra_event(void* ev) { extra_ev_ = ev; }
+  void* extra_ev_ = nullptr;
   // hipGraph replay of the greedy decode step (default on)
   void set_graphs(bool on) { use_graphs_ = on; }
   // workgroup cap of the encoder's GEMM / attention launches while it co-runs with the decode loop (0 = uncapped)

@@ -1937,6 +1937,11 @@ void Model<T, TS>::generate(hipStream_t s, const float* clip_images, const float
   }
   clip_tower(s, clip_images, B);
   std::vector<int> slen, img_pos;
+  if (extra_ev_) {  // extra_embeds were queued on another stream (anyref_set_extra_event): first use is the splice
+    hipEvent_t ev = reinterpret_cast<hipEvent_t>(extra_ev_);
+    extra_ev_ = nullptr;
+    HIP_TRY(hipStreamWaitEvent(s, ev, 0));
+  }
   const int Sp = splice_inputs(s, input_ids, lens, B, Lmax, extra_embeds, extra_slots, n_extra, slen, img_pos);
   for (int b = 0; b < B; ++b)
     if (slen[b] + max_new_tokens > S) throw std::runtime_error("prompt + max_new_tokens exceeds llm_max_seq");
@@ -2074,6 +2079,11 @@ void Model<T, TS>::forward_teacher(hipStream_t s, const float* clip_images, cons
   fork_sam(s, sam_images, B);
   clip_tower(s, clip_images, B);
   std::vector<int> slen, img_pos;
+  if (extra_ev_) {  // extra_embeds were queued on another stream (anyref_set_extra_event): first use is the splice
+    hipEvent_t ev = reinterpret_cast<hipEvent_t>(extra_ev_);
+    extra_ev_ = nullptr;
+    HIP_TRY(hipStreamWaitEvent(s, ev, 0));
+  }
   const int Sp = splice_inputs(s, input_ids, lens, B, Lmax, extra_embeds, extra_slots, n_extra, slen, img_pos);
   llm_prefill(s, B, Sp, slen_dev_, keep_q);
   if (out_logits) {

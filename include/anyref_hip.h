@@ -207,6 +207,13 @@ int anyref_set_overlap(anyref_handle* h, int on);
  * anyref.py:718-822; same arithmetic per prompt, one prompt per mask-decoder call).  0: all masks after the loop. */
 int anyref_set_early_tail(anyref_handle* h, int on);
 
+/* extra_embeds produced on ANOTHER stream (e.g. the ImageBind audio trunk + audio_projector, `anyref_audio_encode` /
+ * `anyref_project_audio` on a stream of the caller's): the next anyref_generate / anyref_forward_teacher on this handle makes
+ * its own stream wait for `event` (a hipEvent_t recorded behind that work) just before the splice -- the first and only
+ * place the rows are read -- so the trunk runs beside the CLIP tower instead of in front of the call.  One-shot: cleared
+ * by the call that consumes it; NULL cancels.  The event must stay alive until that call has been queued. */
+int anyref_set_extra_event(anyref_handle* h, void* event);
+
 /* hipGraph replay of the greedy decode step (default 1): one step is ~170 launches with fixed
  * arguments (position / next token live on the device), captured once per batch size.  0 launches
  * them eagerly; the per-kernel profiler below always runs eagerly. */
