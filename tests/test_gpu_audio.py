@@ -89,6 +89,18 @@ def test_generate_with_raw_mel_through_the_hip_trunk():
     n = ref["hidden"][0].shape[0]
     assert (ex["hidden"][0, :n].cpu() - ref["hidden"][0]).abs().max().item() < 2e-4
     assert (masks[0].cpu() - ref["pred_masks"][0]).abs().max().item() <= 1e-3
+    # the trunk + projector on a stream of their own (the call waits for them at the splice: anyref_set_extra_event, the default)
+    # against the same call with everything on the caller's stream: same kernels, bit-identical results
+    import os
+    os.environ["ANYREF_AUDIO_OVERLAP"] = "0"
+    try:
+        (ids2, masks2, _), ex2 = m.generate(clip, ids[None], sam, sizes, H, W, audios=[mel], max_new_tokens=5, _return_extras=True)
+    finally:
+        del os.environ["ANYREF_AUDIO_OVERLAP"]
+    for _ in range(3):                               # (and back to back: the one-shot event is re-armed per call)
+        (ids3, masks3, _), ex3 = m.generate(clip, ids[None], sam, sizes, H, W, audios=[mel], max_new_tokens=5, _return_extras=True)
+        assert torch.equal(ids3, ids2) and torch.equal(masks3[0], masks2[0]) and torch.equal(ex3["hidden"], ex2["hidden"])
+    assert torch.equal(out_ids, ids2) and torch.equal(masks[0], masks2[0])
 
 
 @pytest.mark.parametrize("mode", ["parity", "parity16", "perf"])
