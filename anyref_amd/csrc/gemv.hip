@@ -423,8 +423,12 @@ __global__ __launch_bounds__(512) void gemv_rows8_kernel(GemvArgs a, int b0, int
     if constexpr (W8) return b * rs + ((kl >> 3) & 1) * pl + (kl >> 4) * 16 + (kl & 7) * 2;
     else return b * rs + kl * 2;
   };
-  if (items > 0) load_item(0, w0);
-  if (items > 1) load_item(1, w1);
+  // (x goes FIRST into the in-order vector-memory queue, as in gemv_kernel: behind two chunks of weights the stage would wait for
+  //  an HBM round trip it does not depend on)
+  auto first_chunks = [&]() __attribute__((always_inline)) {
+    if (items > 0) load_item(0, w0);
+    if (items > 1) load_item(1, w1);
+  };
   float scale[NB];
 #pragma unroll
   for (int b = 0; b < NB; ++b) scale[b] = 1.f;
@@ -445,6 +449,7 @@ __global__ __launch_bounds__(512) void gemv_rows8_kernel(GemvArgs a, int b0, int
         xr[b][i] = (b < nb && k < K) ? *reinterpret_cast<const float4v*>(x + k) : float4v{0.f, 0.f, 0.f, 0.f};
       }
     }
+    first_chunks();
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       float ss = 0.f;
@@ -477,7 +482,7 @@ __global__ __launch_bounds__(512) void gemv_rows8_kernel(GemvArgs a, int b0, int
       }
     }
   }
-  auto stage_plain = [&](int kbase, int klen) __attribute__((always_inline)) {  // f32 -> bf16 copy of x[:, kbase : kbase + klen) (no norm)
+  auto stage_plain = [&](int kbase, int klen, bool then_weights) __attribute__((always_inline)) {  // f32 -> bf16 copy of x[:, kbase : kbase + klen) (no norm)
     // four rows at a time, every load of the four in flight before the first LDS store (a load -> store loop over rows and
     // 2048-column pieces is ~24 dependent L2 round trips: 6 us of a 17 us o_proj launch)
     constexpr int NI = 5;  // float4 per thread and row: stage <= 9472 columns
@@ -494,6 +499,7 @@ __global__ __launch_bounds__(512) void gemv_rows8_kernel(GemvArgs a, int b0, int
           r[b][i] = (bb + b < nb && c < n4) ? *reinterpret_cast<const float4v*>(x + c * 4) : float4v{0.f, 0.f, 0.f, 0.f};
         }
       }
+      if (then_weights && bb == 0) first_chunks();
 #pragma unroll
       for (int b = 0; b < 4; ++b)
 #pragma unroll
@@ -503,7 +509,7 @@ __global__ __launch_bounds__(512) void gemv_rows8_kernel(GemvArgs a, int b0, int
         }
     }
   };
-  if (!a.gain) stage_plain(0, kh0);
+  if (!a.gain) stage_plain(0, kh0, true);
   __syncthreads();
 
   float4v ac[2];  // [batch rows 0-3 | 4-7] of the current row group (two-K-half launches: the wave's only group)
@@ -612,7 +618,7 @@ __global__ __launch_bounds__(512) void gemv_rows8_kernel(GemvArgs a, int b0, int
   run(0, items0);
   if (nkh == 2) {  // every wave of the workgroup, with or without a row group of its own
     __syncthreads();
-    stage_plain(kh0, K - kh0);
+    stage_plain(kh0, K - kh0, false);
     __syncthreads();
     run(items0, items);
   }
