@@ -224,7 +224,9 @@ int anyref_set_graphs(anyref_handle* h, int on);
  * tiles), so that the decode GEMVs -- whose throughput is proportional to the CUs they get -- keep CUs of their own
  * instead of queueing behind 256 resident MFMA workgroups; the encoder's blocks are queued ceil(depth / steps) per
  * decode step, and what is left when the loop ends runs uncapped.  wgs = 0: uncapped, queued whole at the fork
- * (the behaviour for batches > 1).  steps <= 0 keeps the current value.  Results are bit-identical either way. */
+ * (the behaviour for more than 4 images per call; 2 - 4 images are fed the same way at a share of their own, 160
+ * workgroups over 3 steps, which this call does not change).  steps <= 0 keeps the current value.  Results are
+ * bit-identical either way. */
 int anyref_set_side_share(anyref_handle* h, int wgs, int steps);
 
 /*
